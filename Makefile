@@ -1,0 +1,43 @@
+# Top-level build.  `make` = GPU library + host programs + checker.
+#   lib      spmv_openmp_cuda_amd/lib/libspmvhip.so   (hipcc, gfx950)      -- the product
+#   host     spmv_openmp_cuda_amd/lib/libspmvhost.so, bin/SpMV_HIP.elf     (gcc, plain C host side)
+#   oracle   oracle/liboracle.so (+ oracle/_ref when /root/reference exists) -- checker only
+#   harness  tests/harness/test_SpMV_HIP.elf (links product + oracle; test program)
+HIPCC    ?= hipcc
+CC        = gcc
+ARCH     ?= gfx950
+PKG       = spmv_openmp_cuda_amd
+HIPSRC    = $(PKG)/csrc/hip/abi.hip $(PKG)/csrc/hip/synth.hip
+HIPHDR    = $(PKG)/csrc/hip/kernels.hpp $(PKG)/csrc/hip/device_mat.hpp include/spmvHip.h include/spmv_types.h
+HIPFLAGS  = --offload-arch=$(ARCH) -O3 -fPIC -shared -std=c++17 -ffp-contract=off -Wall -Wno-unused-function -Iinclude
+HOSTSRC   = $(wildcard $(PKG)/csrc/host/*.c)
+HOSTLIBSRC= $(filter-out %/main.c,$(HOSTSRC))
+CFLAGS    = -O2 -fopenmp -fPIC -Wall -Wextra -Wno-unused-parameter -Iinclude
+
+all: lib host oracle harness
+
+lib: $(PKG)/lib/libspmvhip.so
+$(PKG)/lib/libspmvhip.so: $(HIPSRC) $(HIPHDR)
+	mkdir -p $(PKG)/lib
+	$(HIPCC) $(HIPFLAGS) -o $@ $(HIPSRC)
+
+host: $(PKG)/lib/libspmvhost.so $(PKG)/bin/SpMV_HIP.elf
+$(PKG)/lib/libspmvhost.so: $(HOSTLIBSRC) $(wildcard include/*.h)
+	mkdir -p $(PKG)/lib
+	$(CC) $(CFLAGS) -shared -o $@ $(HOSTLIBSRC) -lm
+$(PKG)/bin/SpMV_HIP.elf: $(PKG)/csrc/host/main.c $(PKG)/lib/libspmvhost.so $(PKG)/lib/libspmvhip.so
+	mkdir -p $(PKG)/bin
+	$(CC) $(CFLAGS) -o $@ $(PKG)/csrc/host/main.c -L$(PKG)/lib -lspmvhost -lspmvhip -Wl,-rpath,'$$ORIGIN/../lib' -lm
+
+oracle:
+	$(MAKE) -C oracle all
+
+harness: tests/harness/test_SpMV_HIP.elf
+tests/harness/test_SpMV_HIP.elf: tests/harness/spmv_test.c oracle $(PKG)/lib/libspmvhost.so $(PKG)/lib/libspmvhip.so
+	$(CC) $(CFLAGS) -DAVG_TIMES_ITERATION=25 -o $@ tests/harness/spmv_test.c -L$(PKG)/lib -lspmvhost -lspmvhip -Loracle -loracle \
+	    -Wl,-rpath,'$$ORIGIN/../../$(PKG)/lib' -Wl,-rpath,'$$ORIGIN/../../oracle' -lm
+
+clean:
+	rm -f $(PKG)/lib/*.so $(PKG)/bin/*.elf tests/harness/*.elf
+	$(MAKE) -C oracle clean
+.PHONY: all lib host oracle harness clean

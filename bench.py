@@ -1,0 +1,354 @@
+#!/usr/bin/env python3
+"""bench.py -- SpMV GFLOP/s + achieved HBM GB/s on synthetic CSR matrices, 1..8 MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c5|c3|c2|...]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One "step" = one y = A.x over the whole matrix: every rank runs the hot kernel
+(hipSpMVWarpPerRowCSR through the C-ABI) on its nnz-balanced contiguous row
+block and, for N > 1, the ranks all-gather y over RCCL/xGMI so that each ends
+with the full vector (ready to be the next x).  The default workload is
+BASELINE.json configs[4] (power-law CSR, 80 M rows / 1.6 G nnz, max row 50 k),
+the configuration the metric's 1/2/4/8-GPU curve is quoted on; it is kept
+whole at every N (strong scaling).  At N = 1 the same run also measures
+configs[2] (10 M / 200 M) and reports it under "headline_c3".
+
+Rank 0 prints ONE JSON line (contract in the task statement) with two extra
+objects: "roofline" (algorithmic bytes / HIP-event kernel time vs 8 TB/s) and
+"cpu_baseline" (the reference's own spmvRowsBasicCSR from oracle/_ref, or the
+oracle port, timed on this box's host cores on a bounded row sample, and used
+as the checker for the GPU result on those rows).
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK = 8.0e12           # bytes/s, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def log(*a):
+    if int(os.environ.get("RANK", "0")) == 0:
+        print("[bench]", *a, file=sys.stderr, flush=True)
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=25)
+    p.add_argument("--warmup", type=int, default=3)
+    p.add_argument("--workload", default="c5")
+    p.add_argument("--scale", type=float, default=1.0, help="shrink/grow the workload (rows and nnz) by this factor")
+    p.add_argument("--launcher", default="hipSpMVWarpPerRowCSR")
+    p.add_argument("--variant", type=int, default=-1)
+    p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--no-extra", action="store_true", help="skip the secondary workloads measured at N=1")
+    p.add_argument("--cpu-sample-nnz", type=int, default=100_000_000)
+    return p.parse_args()
+
+
+def time_kernel_loop(api, torch, dist, world, step, steps, warmup, ev_pairs):
+    """W untimed + exactly K timed steps, barrier + synchronize on both sides."""
+    for _ in range(warmup):
+        step(None)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(steps):
+        step(ev_pairs[k])
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t1 = time.perf_counter()
+    return t1 - t0
+
+
+def kernel_ms(api, ev_pairs):
+    out = []
+    ms = C.c_float()
+    for a, b in ev_pairs:
+        api.lib.spmvHipEventElapsedMs(a, b, C.byref(ms))
+        out.append(ms.value)
+    return out
+
+
+def measure_single(api, synth, torch, w, launcher, steps, warmup):
+    """1-GPU measurement of workload `w`; returns (dict, context for checks)."""
+    import numpy as np
+    lens = synth.row_lengths(w)
+    irp = synth.prefix(lens)
+    info = synth.describe(w, lens)
+    dm = synth.device_csr(w, irp, 0, w.N)
+    x_host = synth.make_x(w.N, w.cfg)
+    x = torch.from_numpy(x_host).cuda()
+    y = torch.full((w.N,), float("nan"), dtype=torch.float64, device="cuda")
+    fn = api.SPMV_LAUNCHERS[launcher]
+    cfg = api.CONFIG()
+    evs = [(C.c_void_p(), C.c_void_p()) for _ in range(steps)]
+    for a, b in evs:
+        api.lib.spmvHipEventCreate(C.byref(a))
+        api.lib.spmvHipEventCreate(C.byref(b))
+
+    def step(ev):
+        if ev:
+            api.lib.spmvHipEventRecord(ev[0])
+        rc = fn(C.byref(dm.handle), x.data_ptr(), cfg, y.data_ptr())
+        if ev:
+            api.lib.spmvHipEventRecord(ev[1])
+        if rc:
+            raise RuntimeError(launcher + " failed")
+
+    wall = time_kernel_loop(api, torch, None, 1, step, steps, warmup, evs)
+    kms = kernel_ms(api, evs)
+    for a, b in evs:
+        api.lib.spmvHipEventDestroy(a)
+        api.lib.spmvHipEventDestroy(b)
+    nnz = int(irp[-1])
+    bytes_alg = synth.algorithmic_bytes_csr(nnz, w.N, w.N)
+    k_avg = sum(kms) / len(kms) * 1e-3
+    res = {
+        "workload": info, "launcher": launcher,
+        "ms_per_step": wall / steps * 1e3, "kernel_ms_avg": k_avg * 1e3, "kernel_ms_min": min(kms),
+        "gflops": 2.0 * nnz / (wall / steps) * 1e-9,
+        "hbm_gbps": bytes_alg / k_avg * 1e-9, "hbm_frac": bytes_alg / k_avg / HBM_PEAK,
+        "algorithmic_bytes": bytes_alg,
+    }
+    return res, dict(dm=dm, irp=irp, x_host=x_host, y=y, x=x, lens=lens)
+
+
+def cpu_baseline_and_check(api, synth, w, irp, x_host, y_gpu_head, sample_nnz, iters=5):
+    """Time the reference's spmvRowsBasicCSR (oracle/_ref) -- or the oracle port --
+    on the first rows of the workload (<= sample_nnz nnz) with all host cores, and
+    use its y as the checker for the GPU's y on those rows."""
+    import numpy as np
+    from spmv_openmp_cuda_amd.ctypes_defs import ref_CONFIG, ref_spmat
+    rows = int(np.searchsorted(irp, sample_nnz, side="right") - 1)
+    rows = max(1, min(rows, w.N))
+    irp_s = np.ascontiguousarray(irp[:rows + 1], dtype=np.uint64)
+    nnz_s = int(irp_s[-1])
+    ora = C.CDLL(os.path.join(ROOT, "oracle", "liboracle.so"))
+    ja32 = np.empty(nnz_s, dtype=np.uint32)
+    as_ = np.empty(nnz_s, dtype=np.float64)
+    vp = C.c_void_p
+    ora.synthFillCsrRef.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64, vp, vp, vp, C.c_uint64, C.c_uint64, C.c_uint64]
+    ora.synthFillCsrRef(rows, w.N, 0, irp_s.ctypes.data_as(vp), ja32.ctypes.data_as(vp), as_.ctypes.data_as(vp),
+                        synth.SEED_STRUCT + w.cfg, synth.SEED_VAL + w.cfg, w.band)
+    ja64 = ja32.astype(np.uint64)
+    del ja32
+    y_cpu = np.full(rows, np.nan)
+    cores = len(os.sched_getaffinity(0))
+    ref_path = os.path.join(ROOT, "oracle", "_ref", "libspmvref.so")
+    times = []
+    if os.path.exists(ref_path):
+        kind = "reference"
+        ref = C.CDLL(ref_path)
+        ref.refChunksNOOP.restype = vp
+        ref.refSetSchedule(1, 0)                                  # omp_sched_static, like OMP_SCHEDULE=static
+        m = ref_spmat()
+        m.M, m.N, m.NZ = rows, w.N, nnz_s
+        rl = np.diff(irp_s).astype(np.uint64)
+        m.IRP = irp_s.ctypes.data_as(C.POINTER(C.c_ulong))
+        m.JA = ja64.ctypes.data_as(C.POINTER(C.c_ulong))
+        m.AS = as_.ctypes.data_as(C.POINTER(C.c_double))
+        m.RL = rl.ctypes.data_as(C.POINTER(C.c_ulong))
+        cfg = ref_CONFIG()
+        cfg.gridRows = cfg.gridCols = 8
+        cfg.threadNum = ref.refMaxThreads()
+        cfg.chunkDistrbFunc = ref.refChunksNOOP()
+        cores = cfg.threadNum
+        ref.spmvRowsBasicCSR.argtypes = [C.POINTER(ref_spmat), vp, C.POINTER(ref_CONFIG), vp]
+        for _ in range(iters + 1):
+            t0 = time.perf_counter()
+            rc = ref.spmvRowsBasicCSR(C.byref(m), x_host.ctypes.data_as(vp), C.byref(cfg), y_cpu.ctypes.data_as(vp))
+            times.append(time.perf_counter() - t0)
+            assert rc == 0
+    else:
+        kind = "port"
+        ora.oracleSetSchedule(1, 0)
+        cores = ora.oracleMaxThreads()
+        ora.oracleCsrOmp32.argtypes = [C.c_ulong, vp, vp, vp, vp, vp]
+        irp32 = irp_s.astype(np.uint32)
+        ja32 = ja64.astype(np.uint32)
+        for _ in range(iters + 1):
+            t0 = time.perf_counter()
+            ora.oracleCsrOmp32(rows, irp32.ctypes.data_as(vp), ja32.ctypes.data_as(vp), as_.ctypes.data_as(vp),
+                               x_host.ctypes.data_as(vp), y_cpu.ctypes.data_as(vp))
+            times.append(time.perf_counter() - t0)
+    times = times[1:]                                             # first pass = page-in
+    t = sum(times) / len(times)
+    diff = np.abs(y_cpu - y_gpu_head[:rows])
+    parity = {"rows_checked": rows, "max_abs_diff": float(np.nanmax(diff)), "gate_abs": 7e-4,
+              "nan_in_gpu_y": bool(np.isnan(y_gpu_head[:rows]).any()),
+              "ok": bool(not np.isnan(y_gpu_head[:rows]).any() and np.nanmax(diff) <= 7e-4)}
+    base = {"value": 2.0 * nnz_s / t * 1e-9, "unit": "GFLOP/s", "cores": int(cores), "kind": kind,
+            "sample": f"rows [0,{rows}) of the workload = {nnz_s} nnz, x full length, {len(times)} timed passes of "
+                      f"spmvRowsBasicCSR, OMP schedule static, {t * 1e3:.2f} ms/pass",
+            "hbm_like_gbps": synth.algorithmic_bytes_csr(nnz_s, rows, w.N) / t * 1e-9}
+    return base, parity
+
+
+def main():
+    args = parse()
+    import numpy as np
+    import torch                      # BEFORE the HIP library: one HIP runtime per process (see api.py)
+    import torch.distributed as dist
+    world = args.gpus
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        assert int(os.environ.get("WORLD_SIZE", "1")) == world, "launch with torch.distributed.run --nproc-per-node N"
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    else:
+        torch.cuda.set_device(0)
+    from spmv_openmp_cuda_amd import api, synth
+    api.spmvHipInit(local)
+    api.lib.spmvHipSetStream(C.c_void_p(torch.cuda.current_stream().cuda_stream))
+    api.lib.spmvHipSetSync(0)
+    if args.variant >= 0:
+        api.set_variant(args.launcher, args.variant)
+
+    w = synth.WORKLOADS[args.workload]
+    if args.scale != 1.0:
+        w = synth.scaled(w, args.scale)
+    steps, warmup = args.steps, args.warmup
+    t_setup = time.perf_counter()
+
+    extra = {}
+    if world == 1:
+        res, ctx = measure_single(api, synth, torch, w, args.launcher, steps, warmup)
+        log(f"{w.name}: {res['gflops']:.1f} GFLOP/s  kernel {res['kernel_ms_avg']:.3f} ms  "
+            f"{res['hbm_gbps']:.0f} GB/s = {100 * res['hbm_frac']:.1f}% of 8 TB/s   (setup {time.perf_counter() - t_setup:.1f}s)")
+        cpu_base, parity = None, None
+        if not args.no_cpu_baseline:
+            head_rows = min(w.N, 8_000_000)
+            y_head = ctx["y"][:head_rows].cpu().numpy()
+            cpu_base, parity = cpu_baseline_and_check(api, synth, w, ctx["irp"], ctx["x_host"], y_head,
+                                                      args.cpu_sample_nnz)
+            log("cpu_baseline", cpu_base, "parity", parity)
+        ctx["dm"].free()
+        del ctx
+        torch.cuda.empty_cache()
+        if not args.no_extra:
+            for key in ("c3", "c3b", "c2"):
+                if key == args.workload:
+                    continue
+                we = synth.WORKLOADS[key]
+                if args.scale != 1.0:
+                    we = synth.scaled(we, args.scale)
+                launcher = "hipSpMVRowsCSR" if key.startswith("c2") else args.launcher
+                r, c = measure_single(api, synth, torch, we, launcher, steps, warmup)
+                c["dm"].free()
+                del c
+                torch.cuda.empty_cache()
+                extra[key] = r
+                log(f"{we.name} [{launcher}]: {r['gflops']:.1f} GFLOP/s  kernel {r['kernel_ms_avg']:.3f} ms  "
+                    f"{100 * r['hbm_frac']:.1f}% of 8 TB/s")
+        line = {
+            "metric": "spmv_gflops", "value": res["gflops"], "unit": "GFLOP/s", "n_gpus": 1, "steps": steps,
+            "warmup": warmup, "ms_per_step": res["ms_per_step"], "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": res["workload"]["workload"], **{k: v for k, v in res["workload"].items() if k != "workload"},
+                       "kernel": args.launcher, "parallelism": "1 GPU"},
+            "hbm_gbps": res["hbm_gbps"], "hbm_roofline_frac": res["hbm_frac"],
+            "roofline": {"bound": "hbm", "achieved": res["hbm_gbps"], "peak": HBM_PEAK * 1e-9, "unit": "GB/s",
+                         "frac": res["hbm_frac"], "traffic": None, "kernel": "csr_stream_kernel",
+                         "algorithmic_bytes_per_launch": res["algorithmic_bytes"],
+                         "kernel_ms_avg": res["kernel_ms_avg"]},
+        }
+        if cpu_base:
+            line["cpu_baseline"] = cpu_base
+            line["parity"] = parity
+        if "c3" in extra:
+            line["headline_c3"] = extra["c3"]
+        for k in ("c3b", "c2"):
+            if k in extra:
+                line["extra_" + k] = extra[k]
+        print(json.dumps(line), flush=True)
+        api.spmvHipFinalize()
+        return
+
+    # ------------------------------------------------------------------ N > 1
+    lens = synth.row_lengths(w)
+    irp = synth.prefix(lens)
+    info = synth.describe(w, lens)
+    del lens
+    bounds = api.partition_rows(irp, world).astype(np.int64)
+    rows_per = np.diff(bounds)
+    max_rows = int(rows_per.max())
+    r0, r1 = int(bounds[rank]), int(bounds[rank + 1])
+    dm = synth.device_csr(w, irp, r0, r1)
+    nnz_total = int(irp[-1])
+    nnz_local = int(irp[r1] - irp[r0])
+    x_host = synth.make_x(w.N, w.cfg)
+    x = torch.from_numpy(x_host).cuda()
+    del x_host
+    ypad = torch.full((world * max_rows,), float("nan"), dtype=torch.float64, device="cuda")
+    y = torch.full((w.N,), float("nan"), dtype=torch.float64, device="cuda")
+    slot = ypad[rank * max_rows:(rank + 1) * max_rows]
+    bounds_u = np.ascontiguousarray(bounds, dtype=np.uint64)
+    equal_blocks = bool((rows_per == max_rows).all())
+    fn = api.SPMV_LAUNCHERS[args.launcher]
+    cfg = api.CONFIG()
+    evs = [(C.c_void_p(), C.c_void_p()) for _ in range(steps)]
+    for a, b in evs:
+        api.lib.spmvHipEventCreate(C.byref(a))
+        api.lib.spmvHipEventCreate(C.byref(b))
+
+    def step(ev):
+        if ev:
+            api.lib.spmvHipEventRecord(ev[0])
+        rc = fn(C.byref(dm.handle), x.data_ptr(), cfg, slot.data_ptr())
+        if ev:
+            api.lib.spmvHipEventRecord(ev[1])
+        if rc:
+            raise RuntimeError(args.launcher + " failed")
+        dist.all_gather_into_tensor(ypad, slot)                 # RCCL over xGMI, in place
+        api.lib.spmvHipCompactRows(y.data_ptr(), ypad.data_ptr(), bounds_u.ctypes.data_as(C.c_void_p), world, max_rows)
+
+    wall = time_kernel_loop(api, torch, dist, world, step, steps, warmup, evs)
+    kms = kernel_ms(api, evs)
+    t = torch.tensor([wall, sum(kms) / len(kms)], dtype=torch.float64, device="cuda")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    wall_max, kernel_ms_max = float(t[0]), float(t[1])
+    # cross-rank consistency: every rank must hold the same full y, with no NaN left
+    chk = torch.stack([y.sum(), y.abs().sum(), torch.isnan(y).sum().to(torch.float64)])
+    chk_all = [torch.empty_like(chk) for _ in range(world)]
+    dist.all_gather(chk_all, chk)
+    same = all(torch.equal(c, chk_all[0]) for c in chk_all)
+    if rank == 0:
+        bytes_alg_local = synth.algorithmic_bytes_csr(nnz_local, r1 - r0, w.N)
+        bytes_alg_total = synth.algorithmic_bytes_csr(nnz_total, w.N, w.N)
+        k_avg = kernel_ms_max * 1e-3
+        line = {
+            "metric": "spmv_gflops", "value": 2.0 * nnz_total / (wall_max / steps) * 1e-9, "unit": "GFLOP/s",
+            "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": wall_max / steps * 1e3,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": info["workload"], **{k: v for k, v in info.items() if k != "workload"},
+                       "kernel": args.launcher,
+                       "parallelism": f"{world} nnz-balanced row blocks + RCCL all-gather(y)" +
+                                      ("" if equal_blocks else " (padded blocks + compaction)")},
+            "hbm_gbps": bytes_alg_total / (wall_max / steps) * 1e-9,
+            "hbm_roofline_frac": bytes_alg_total / (wall_max / steps) / (HBM_PEAK * world),
+            "roofline": {"bound": "hbm", "achieved": bytes_alg_local / k_avg * 1e-9, "peak": HBM_PEAK * 1e-9,
+                         "unit": "GB/s", "frac": bytes_alg_local / k_avg / HBM_PEAK, "traffic": None,
+                         "kernel": "csr_stream_kernel", "algorithmic_bytes_per_launch": bytes_alg_local,
+                         "kernel_ms_avg": kernel_ms_max, "note": "per-rank kernel, slowest rank"},
+            "gather_ms_per_step": wall_max / steps * 1e3 - kernel_ms_max,
+            "parity": {"all_ranks_hold_identical_y": bool(same), "nan_left": float(chk_all[0][2])},
+        }
+        print(json.dumps(line), flush=True)
+    dist.barrier()
+    dm.free()
+    api.spmvHipFinalize()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

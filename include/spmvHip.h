@@ -1,0 +1,164 @@
+/*
+ * spmvHip.h -- C-ABI of libspmvhip.so: the MI355X (gfx950) replacement for the
+ * reference's CUDA path.  Plain C, plain pointers and sizes; no C++/torch types.
+ *
+ * Every entry point returns EXIT_SUCCESS (0) / EXIT_FAILURE (1) like the
+ * reference's host functions (cudaUtils.cu:45,54; SpMV_CSR_OMP.c:35,61), prints
+ * its diagnostics on stderr and NEVER calls exit() (the reference's
+ * checkCudaErrors does, cudaUtils.h:26-34 -- not reproduced).
+ *
+ * What each group replaces in the reference (paths relative to its root):
+ *   upload / free ......... src/include/cudaUtils.h:60-78, src/commons/cudaUtils.cu:20-98
+ *   SpMV launchers ........ the five __global__ kernels of src/SpMV_CUDA.cu:33-135 as the
+ *                           drivers invoke them: f<<<grid,block>>>(dMat,dVect,Conf,dOutV)
+ *                           (src/main.cu:233, test/SpMV_test.cu:112)
+ *   vectors / lifecycle ... the cudaMalloc/cudaMemcpy/cudaFree calls the drivers make inline
+ *                           (src/main.cu:195-199,245-247,277-280)
+ *   sharding .............. new (the reference is single-GPU); see DESIGN.md "Multi-GPU"
+ */
+#ifndef SPMV_HIP_H
+#define SPMV_HIP_H
+
+#include "spmv_types.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ------------------------------------------------------------------ lifecycle */
+/* Select device `dev` for the calling thread and check the caller was compiled
+ * against the same struct layouts.  Must be called once before anything else. */
+int spmvHipInit(int dev, size_t sizeofSpmat, size_t sizeofConfig);
+int spmvHipFinalize(void);
+/* number of visible devices, or -1 */
+int spmvHipDeviceCount(void);
+/* Stream (hipStream_t passed as void*) used by all later launches/copies of the
+ * calling process; NULL = the default stream. */
+int spmvHipSetStream(void* stream);
+/* sync != 0 (default): every SpMV launcher waits for completion before it
+ * returns and stores the device time in `ElapsedInternal`-style seconds
+ * retrievable with spmvHipLastKernelSeconds() -- the behaviour of the
+ * reference drivers (launch; cudaDeviceSynchronize; main.cu:233-238).
+ * sync == 0: launchers only enqueue (for timed loops and graph capture). */
+int spmvHipSetSync(int sync);
+double spmvHipLastKernelSeconds(void);
+/* launch shape of the most recent SpMV launcher call */
+int spmvHipLastLaunch(spmvDim3* grid, spmvDim3* block);
+int spmvHipDeviceSynchronize(void);
+
+/* ------------------------------------------------------------- dense vectors */
+int spmvHipVecAlloc(double** dVec, size_t n);
+int spmvHipVecFree(double* dVec);
+int spmvHipVecUp(double* dVec, const double* hVec, size_t n);
+int spmvHipVecDown(double* hVec, const double* dVec, size_t n);
+/* fill with a 64-bit pattern (e.g. a NaN payload to poison y before a launch) */
+int spmvHipVecFill(double* dVec, size_t n, uint64_t pattern);
+
+/* raw device bytes (device-format index arrays built on the GPU) */
+int spmvHipMalloc(void** dPtr, size_t bytes);
+int spmvHipFree(void* dPtr);
+int spmvHipMemcpyUp(void* dDst, const void* hSrc, size_t bytes);
+int spmvHipMemcpyDown(void* hDst, const void* dSrc, size_t bytes);
+
+/* ------------------------------------------------------------- matrix upload */
+/* Host CSR -> device (cudaUtils.cu:20-55).  `dMat` is caller-owned host memory
+ * that becomes the device handle.  Column ids are narrowed to 32 bit, row
+ * pointers to 32 bit when NZ < 2^32; row blocks for the LDS-stream kernel are
+ * computed here.  host->RL may be NULL. */
+int spMatCpyCSR(spmat* host, spmat* dMat);
+/* Host ELL -> device (cudaUtils.cu:56-98).  Accepts the row-major matrix the
+ * loader produces, or the output of ellTranspose() (recognised the same way
+ * the reference kernels do: after transposition M holds the slot count and
+ * MAX_ROW_NZ the row count, sparseUtils.c:168-171) -- pass `transposed` = 1 for
+ * the latter.  Pitch = row length rounded up to 64 elements; pitchJA/pitchAS
+ * are stored in elements as the reference does (cudaUtils.cu:81-83). */
+int spMatCpyELL(spmat* host, spmat* dMat);
+int spMatCpyELLTransposed(spmat* hostT, spmat* dMat);
+/* Release the device arrays behind a handle (cudaUtils.h:70-78). */
+int hipFreeSpmat(spmat* dMat);
+
+/* Adopt arrays that are ALREADY on the device in device format (u32 columns,
+ * u32 or u64 row pointers) -- used by the on-device synthetic generator and by
+ * callers that assemble matrices on the GPU.  The handle takes ownership of
+ * nothing: the caller frees the arrays after hipFreeSpmat(). `irpBytes` is 4 or 8.
+ * `hIRP` is the same row-pointer array on the host (needed for the row-block
+ * analysis); it may be NULL, in which case it is downloaded. */
+int spmvHipAdoptCSR(spmat* dMat, ulong M, ulong N, ulong NZ,
+                    const void* dIRP, int irpBytes, const uint32_t* dJA,
+                    const double* dAS, const void* hIRP);
+
+/* --------------------------------------------------------------- SpMV on GPU */
+/* y = A x with A, x, y resident on the device.  (mat, x, CONFIG by value, y):
+ * the parameter list of the reference's SPMV_CUDA typedef (SpMV.h:119-120). */
+typedef int (SPMV_HIP)(spmat*, double*, CONFIG, double*);
+typedef int (*SPMV_HIP_INTERF)(spmat*, double*, CONFIG, double*);
+
+SPMV_HIP hipSpMVRowsCSR;                  /* <- cudaSpMVRowsCSR                  SpMV_CUDA.cu:33-49   */
+SPMV_HIP hipSpMVWarpPerRowCSR;            /* <- cudaSpMVWarpPerRowCSR            SpMV_CUDA.cu:52-73   */
+SPMV_HIP hipSpMVRowsELL;                  /* <- cudaSpMVRowsELL (transposed)     SpMV_CUDA.cu:79-96   */
+SPMV_HIP hipSpMVRowsELLNNTransposed;      /* <- cudaSpMVRowsELLNNTransposed      SpMV_CUDA.cu:99-115  */
+SPMV_HIP hipSpMVWarpsPerRowELLNTrasposed; /* <- cudaSpMVWarpsPerRowELLNTrasposed SpMV_CUDA.cu:116-135 */
+
+/* Kernel variants behind each launcher (for A/B measurement; default = best):
+ *   hipSpMVRowsCSR        0 = one thread walks its row in global memory ("scalar")
+ *                         1 = LDS-stream: coalesced span load, one thread sums its row
+ *                             in ascending-j order (bit-identical to the serial oracle)
+ *   hipSpMVWarpPerRowCSR  0 = one wavefront per row, __shfl_down tree
+ *                         1 = adaptive: LDS segmented reduction for short rows,
+ *                             wavefront-/workgroup-per-row for long ones
+ * Returns EXIT_FAILURE for an unknown (launcher, variant). */
+int spmvHipSetVariant(const char* launcher, int variant);
+/* Use the RL array for ELL early exit (1, default when RL was uploaded) or walk
+ * all MAX_ROW_NZ slots like the reference's cudaSpMVRowsELL (0). */
+int spmvHipSetEllRowLens(int useRowLens);
+
+/* SPMV_INTERF-compatible wrappers (host vectors in/out, matrix uploaded and
+ * cached on first use, keyed by the host spmat address) so the GPU path can sit
+ * in SpmvCSRFuncs[]-style tables next to the OpenMP variants (SpMV.h:146-159). */
+int spmvHipRowsCSR(spmat* mat, double* x, CONFIG* cfg, double* y);
+int spmvHipWarpPerRowCSR(spmat* mat, double* x, CONFIG* cfg, double* y);
+int spmvHipRowsELL(spmat* mat, double* x, CONFIG* cfg, double* y);
+int spmvHipWarpsPerRowELL(spmat* mat, double* x, CONFIG* cfg, double* y);
+int spmvHipDropCache(void);
+
+/* ------------------------------------------------------- events (measurement) */
+int spmvHipEventCreate(void** ev);
+int spmvHipEventDestroy(void* ev);
+int spmvHipEventRecord(void* ev);                 /* on the stream set above */
+int spmvHipEventElapsedMs(void* evStart, void* evStop, float* ms);  /* syncs on evStop */
+
+/* ------------------------------------------------------------------ sharding */
+/* nnz-balanced contiguous row blocks: bounds[p]..bounds[p+1] are the rows of
+ * part p (bounds has nParts+1 entries).  IRP is a host row-pointer array. */
+int spmvHipPartitionRows(const ulong* IRP, ulong M, int nParts, ulong* bounds);
+/* Extract rows [r0,r1) of a host CSR matrix as a new host CSR (local IRP
+ * rebased to 0, global column ids kept).  Free with freeSpmat(). */
+spmat* spmvHipRowBlockCSR(const spmat* host, ulong r0, ulong r1);
+/* After an all-gather of equally padded row blocks (dYPad = nParts blocks of
+ * maxRows doubles, block p holding rows bounds[p]..bounds[p+1]) copy the rows
+ * back to back into dY -- nParts device-to-device copies on the library stream. */
+int spmvHipCompactRows(double* dY, const double* dYPad, const ulong* bounds, int nParts, ulong maxRows);
+/* Single-process multi-device path (C drivers): shard, upload one block per
+ * device, replicate x, run `mode` on every device concurrently, gather y with
+ * an RCCL all-gather over xGMI.  bench.py uses one process per GPU instead and
+ * calls the single-device entry points + torch.distributed (RCCL). */
+int spmvHipShardCSR(spmat* host, int nDev, void** shardHandle);
+int spmvHipSpMVSharded(void* shardHandle, const double* hX, int mode, double* hY,
+                       double* kernelSec, double* gatherSec);
+int spmvHipShardFree(void* shardHandle);
+
+/* ------------------------------------------------- synthetic matrices on device */
+/* Fill JA/AS of a CSR whose row pointers are given (device arrays, device
+ * format), for global rows [rowOffset, rowOffset+M): DESIGN.md "Synthetic
+ * inputs".  band == 0: columns stratified-uniform over [0,N); band > 0: columns
+ * stratified over [r-band, r+band] clipped to [0,N). */
+int spmvHipSynthFillCSR(ulong M, ulong N, ulong rowOffset, const void* dIRP, int irpBytes,
+                        uint32_t* dJA, double* dAS, uint64_t seedStruct, uint64_t seedVal,
+                        ulong band);
+/* (the dense vector x is generated on the host -- it needs sin(), whose last
+ * bit differs between libm and the device -- and uploaded with spmvHipVecUp) */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SPMV_HIP_H */

@@ -1,0 +1,55 @@
+/*
+ * utils.h -- vector I/O, run configuration from the environment, the parity
+ * gate and timing statistics.  Surface of the reference's
+ * src/include/utils.h:21-108 restricted to what the SpMV path uses
+ * (shell-out decompression, utils.c:433-462, is out of scope).
+ */
+#ifndef SPMV_UTILS_H
+#define SPMV_UTILS_H
+
+#include "spmv_types.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DOUBLE_STR_FORMAT "%25le\n"
+#define GRID_ROWS "GRID_ROWS"
+#define GRID_COLS "GRID_COLS"
+
+extern int urndFd;
+int init_urndfd(void);
+
+/* raw double[size] dump / text dump, one DOUBLE_STR_FORMAT line per element */
+int     writeDoubleVector(char* fpath, double* v, ulong size);
+int     writeDoubleVectorAsStr(char* fpath, double* v, ulong size);
+/* raw / text vector files; *size in = expected length hint (0 = unknown),
+ * *size out = elements read.  NULL on error. */
+double* readDoubleVector(char* fpath, ulong* size);
+double* readDoubleVectorStr(char* fpath, ulong* size);
+
+/* GRID_ROWS / GRID_COLS from the environment; EXIT_SUCCESS if any was set */
+int getConfig(CONFIG* conf);
+
+/* x_i = sin(8 random bytes reinterpreted as double) * MAXRND (utils.c:322-329).
+ * The reference can emit NaN here (sin of NaN/Inf bit patterns), which makes
+ * its diff check vacuous; this version redraws until the value is finite. */
+int fillRndVector(ulong size, double* v);
+
+/*
+ * Parity gate (utils.c:362-393): EXIT_FAILURE iff some |a_i - b_i| exceeds
+ * DOUBLE_DIFF_THREASH.  `a` = expected, `b` = candidate; *diffMax (optional)
+ * receives the signed difference of largest magnitude.  Unlike the reference,
+ * a NaN on either side FAILS (there `NaN > thresh` is false, so NaN passes).
+ */
+int doubleVectorsDiff(double* a, double* b, ulong n, double* diffMax);
+
+/* out[0] = mean, out[1] = population variance (utils.c:340-348) */
+void statsAvgVar(double* values, uint numVals, double* out);
+
+void printVector(double* v, ulong size);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

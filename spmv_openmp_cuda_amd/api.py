@@ -1,0 +1,322 @@
+"""Python mirror of the C driver surface (include/spmvHip.h, include/SpMV.h).
+
+Same names, argument meaning and error behaviour (0 = EXIT_SUCCESS, 1 =
+EXIT_FAILURE, diagnostics on stderr) as the C entry points, which in turn mirror
+the reference (src/include/SpMV.h:119-142, src/include/cudaUtils.h:60-78).
+Everything numeric happens in libspmvhip.so; numpy is only used to marshal host
+arrays.  The library is REQUIRED: there is no fallback implementation.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from .ctypes_defs import CONFIG, POISON_NAN, SPMAT_TAG_ELL_TRANSPOSED, spmat, spmvDim3
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libspmvhip.so")
+HOSTLIB_PATH = os.path.join(_HERE, "lib", "libspmvhost.so")
+
+
+class SpmvHipError(RuntimeError):
+    pass
+
+
+def _load(path):
+    if not os.path.exists(path):
+        raise SpmvHipError(
+            f"{path} is missing: build it with `make lib host` (or __graft_entry__.build()). "
+            "This package has no CPU fallback.")
+    return C.CDLL(path, mode=C.RTLD_GLOBAL)
+
+
+lib = _load(LIB_PATH)
+hostlib = _load(HOSTLIB_PATH)
+
+_vp, _sz, _u64, _i = C.c_void_p, C.c_size_t, C.c_uint64, C.c_int
+_SPMV_ARGS = [C.POINTER(spmat), _vp, CONFIG, _vp]
+_sigs = {
+    "spmvHipInit": ([_i, _sz, _sz], _i), "spmvHipFinalize": ([], _i), "spmvHipDeviceCount": ([], _i),
+    "spmvHipSetStream": ([_vp], _i), "spmvHipSetSync": ([_i], _i),
+    "spmvHipLastKernelSeconds": ([], C.c_double),
+    "spmvHipLastLaunch": ([C.POINTER(spmvDim3), C.POINTER(spmvDim3)], _i),
+    "spmvHipDeviceSynchronize": ([], _i),
+    "spmvHipVecAlloc": ([C.POINTER(_vp), _sz], _i), "spmvHipVecFree": ([_vp], _i),
+    "spmvHipVecUp": ([_vp, _vp, _sz], _i), "spmvHipVecDown": ([_vp, _vp, _sz], _i),
+    "spmvHipVecFill": ([_vp, _sz, _u64], _i),
+    "spmvHipMalloc": ([C.POINTER(_vp), _sz], _i), "spmvHipFree": ([_vp], _i),
+    "spmvHipMemcpyUp": ([_vp, _vp, _sz], _i), "spmvHipMemcpyDown": ([_vp, _vp, _sz], _i),
+    "spMatCpyCSR": ([C.POINTER(spmat), C.POINTER(spmat)], _i),
+    "spMatCpyELL": ([C.POINTER(spmat), C.POINTER(spmat)], _i),
+    "spMatCpyELLTransposed": ([C.POINTER(spmat), C.POINTER(spmat)], _i),
+    "hipFreeSpmat": ([C.POINTER(spmat)], _i),
+    "spmvHipAdoptCSR": ([C.POINTER(spmat), C.c_ulong, C.c_ulong, C.c_ulong, _vp, _i, _vp, _vp, _vp], _i),
+    "hipSpMVRowsCSR": (_SPMV_ARGS, _i), "hipSpMVWarpPerRowCSR": (_SPMV_ARGS, _i),
+    "hipSpMVRowsELL": (_SPMV_ARGS, _i), "hipSpMVRowsELLNNTransposed": (_SPMV_ARGS, _i),
+    "hipSpMVWarpsPerRowELLNTrasposed": (_SPMV_ARGS, _i),
+    "spmvHipSetVariant": ([C.c_char_p, _i], _i), "spmvHipSetEllRowLens": ([_i], _i),
+    "spmvHipRowsCSR": ([C.POINTER(spmat), _vp, C.POINTER(CONFIG), _vp], _i),
+    "spmvHipWarpPerRowCSR": ([C.POINTER(spmat), _vp, C.POINTER(CONFIG), _vp], _i),
+    "spmvHipRowsELL": ([C.POINTER(spmat), _vp, C.POINTER(CONFIG), _vp], _i),
+    "spmvHipWarpsPerRowELL": ([C.POINTER(spmat), _vp, C.POINTER(CONFIG), _vp], _i),
+    "spmvHipDropCache": ([], _i),
+    "spmvHipEventCreate": ([C.POINTER(_vp)], _i), "spmvHipEventDestroy": ([_vp], _i),
+    "spmvHipEventRecord": ([_vp], _i), "spmvHipEventElapsedMs": ([_vp, _vp, C.POINTER(C.c_float)], _i),
+    "spmvHipPartitionRows": ([_vp, C.c_ulong, _i, _vp], _i),
+    "spmvHipRowBlockCSR": ([C.POINTER(spmat), C.c_ulong, C.c_ulong], C.POINTER(spmat)),
+    "spmvHipSynthFillCSR": ([C.c_ulong, C.c_ulong, C.c_ulong, _vp, _i, _vp, _vp, _u64, _u64, C.c_ulong], _i),
+    "spmvHipCompactRows": ([_vp, _vp, _vp, _i, C.c_ulong], _i),
+}
+for _name, (_args, _res) in _sigs.items():
+    _f = getattr(lib, _name)
+    _f.argtypes, _f.restype = _args, _res
+
+_hsigs = {
+    "MMtoCSR": ([C.c_char_p], C.POINTER(spmat)), "MMtoELL": ([C.c_char_p], C.POINTER(spmat)),
+    "freeSpmat": ([C.POINTER(spmat)], None),
+    "ellTranspose": ([C.POINTER(spmat)], C.POINTER(spmat)),
+    "csrToEll": ([C.POINTER(spmat)], C.POINTER(spmat)),
+    "doubleVectorsDiff": ([_vp, _vp, C.c_ulong, C.POINTER(C.c_double)], _i),
+    "statsAvgVar": ([_vp, C.c_uint, _vp], None),
+    "fillRndVector": ([C.c_ulong, _vp], _i),
+    "spmvModeFromString": ([C.c_char_p], _i),
+    "writeDoubleVector": ([C.c_char_p, _vp, C.c_ulong], _i),
+    "readDoubleVector": ([C.c_char_p, C.POINTER(C.c_ulong)], C.POINTER(C.c_double)),
+    "spmvSynthPowerLawLengths": ([_u64, _u64, C.c_uint32, _u64, _vp, C.POINTER(C.c_double)], _i),
+    "spmvSynthPrefix": ([_vp, _u64, _vp], _u64),
+    "spmvSynthMakeX": ([_u64, _u64, _vp], None),
+    "spmvSynthPerm": ([_u64, _u64, _u64], _u64),
+}
+for _name, (_args, _res) in _hsigs.items():
+    _f = getattr(hostlib, _name)
+    _f.argtypes, _f.restype = _args, _res
+
+SPMV_LAUNCHERS = {
+    "hipSpMVRowsCSR": lib.hipSpMVRowsCSR,
+    "hipSpMVWarpPerRowCSR": lib.hipSpMVWarpPerRowCSR,
+    "hipSpMVRowsELL": lib.hipSpMVRowsELL,
+    "hipSpMVRowsELLNNTransposed": lib.hipSpMVRowsELLNNTransposed,
+    "hipSpMVWarpsPerRowELLNTrasposed": lib.hipSpMVWarpsPerRowELLNTrasposed,
+}
+
+
+def _check(rc, what):
+    if rc != 0:
+        raise SpmvHipError(f"{what} failed (EXIT_FAILURE) -- see stderr")
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+# ----------------------------------------------------------------- lifecycle
+def spmvHipInit(dev=0):
+    _check(lib.spmvHipInit(int(dev), C.sizeof(spmat), C.sizeof(CONFIG)), "spmvHipInit")
+
+
+def spmvHipFinalize():
+    lib.spmvHipFinalize()
+
+
+# ----------------------------------------------------------------- host matrices
+class HostCSR:
+    """A host `spmat` in CSR form over numpy arrays (64-bit indices like the
+    reference's loader output).  Keeps the arrays alive."""
+
+    def __init__(self, M, N, IRP, JA, AS, with_row_lens=True):
+        self.IRP = np.ascontiguousarray(IRP, dtype=np.uint64)
+        self.JA = np.ascontiguousarray(JA, dtype=np.uint64)
+        self.AS = np.ascontiguousarray(AS, dtype=np.float64)
+        assert self.IRP.shape == (M + 1,) and self.JA.shape == self.AS.shape
+        self.RL = np.diff(self.IRP).astype(np.uint64) if with_row_lens else None
+        s = spmat()
+        s.M, s.N, s.NZ = M, N, int(self.JA.size)
+        s.IRP = self.IRP.ctypes.data_as(C.POINTER(C.c_ulong))
+        s.JA = self.JA.ctypes.data_as(C.POINTER(C.c_ulong))
+        s.AS = self.AS.ctypes.data_as(C.POINTER(C.c_double))
+        if self.RL is not None:
+            s.RL = self.RL.ctypes.data_as(C.POINTER(C.c_ulong))
+        self.struct = s
+
+    @property
+    def M(self):
+        return self.struct.M
+
+    @property
+    def N(self):
+        return self.struct.N
+
+    @property
+    def NZ(self):
+        return self.struct.NZ
+
+    def to_ell(self, with_row_lens=True):
+        """Row-major ELL with {JA=0, AS=0} padding (parser.c:246-253 semantics)."""
+        M = self.M
+        lens = np.diff(self.IRP).astype(np.int64)
+        K = int(lens.max()) if M else 0
+        JA = np.zeros((M, K), dtype=np.uint64)
+        AS = np.zeros((M, K), dtype=np.float64)
+        if self.NZ:
+            rows = np.repeat(np.arange(M), lens)
+            pos = np.arange(self.NZ) - np.repeat(self.IRP[:-1].astype(np.int64), lens)
+            JA[rows, pos] = self.JA
+            AS[rows, pos] = self.AS
+        return HostELL(M, self.N, self.NZ, K, JA, AS, lens.astype(np.uint64) if with_row_lens else None)
+
+
+class HostELL:
+    """A host `spmat` in ELL form.  `transposed` follows the reference's
+    ellTranspose field convention (sparseUtils.c:168-171)."""
+
+    def __init__(self, M, N, NZ, K, JA, AS, RL=None, transposed=False):
+        self.JA = np.ascontiguousarray(JA, dtype=np.uint64)
+        self.AS = np.ascontiguousarray(AS, dtype=np.float64)
+        self.RL = None if RL is None else np.ascontiguousarray(RL, dtype=np.uint64)
+        self.rows, self.slots, self.transposed = M, K, transposed
+        s = spmat()
+        s.NZ = NZ
+        if transposed:
+            s.M, s.N, s.MAX_ROW_NZ = K, M, M
+            s.dev = SPMAT_TAG_ELL_TRANSPOSED
+        else:
+            s.M, s.N, s.MAX_ROW_NZ = M, N, K
+        s.JA = self.JA.ctypes.data_as(C.POINTER(C.c_ulong))
+        s.AS = self.AS.ctypes.data_as(C.POINTER(C.c_double))
+        if self.RL is not None:
+            s.RL = self.RL.ctypes.data_as(C.POINTER(C.c_ulong))
+        self.struct = s
+        self._N = N
+
+    def transpose(self):
+        """ellTranspose (sparseUtils.c:145-185) on numpy arrays."""
+        assert not self.transposed
+        return HostELL(self.rows, self._N, self.struct.NZ, self.slots,
+                       self.JA.reshape(self.rows, self.slots).T.copy(),
+                       self.AS.reshape(self.rows, self.slots).T.copy(), self.RL, transposed=True)
+
+
+# ----------------------------------------------------------------- device objects
+class DeviceVector:
+    def __init__(self, n):
+        self.n = int(n)
+        p = C.c_void_p()
+        _check(lib.spmvHipVecAlloc(C.byref(p), self.n), "spmvHipVecAlloc")
+        self.ptr = p
+
+    def up(self, host):
+        host = np.ascontiguousarray(host, dtype=np.float64)
+        assert host.size == self.n
+        _check(lib.spmvHipVecUp(self.ptr, _ptr(host), self.n), "spmvHipVecUp")
+        return self
+
+    def down(self):
+        out = np.empty(self.n, dtype=np.float64)
+        _check(lib.spmvHipVecDown(_ptr(out), self.ptr, self.n), "spmvHipVecDown")
+        return out
+
+    def poison(self):
+        _check(lib.spmvHipVecFill(self.ptr, self.n, POISON_NAN), "spmvHipVecFill")
+
+    def free(self):
+        if self.ptr:
+            lib.spmvHipVecFree(self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class DeviceBuffer:
+    """Raw device bytes (for device-format matrices built on the GPU)."""
+
+    def __init__(self, nbytes):
+        self.nbytes = int(nbytes)
+        p = C.c_void_p()
+        _check(lib.spmvHipMalloc(C.byref(p), max(self.nbytes, 1)), "spmvHipMalloc")
+        self.ptr = p
+
+    def up(self, host):
+        host = np.ascontiguousarray(host)
+        assert host.nbytes == self.nbytes
+        _check(lib.spmvHipMemcpyUp(self.ptr, _ptr(host), self.nbytes), "spmvHipMemcpyUp")
+        return self
+
+    def down(self, dtype):
+        out = np.empty(self.nbytes // np.dtype(dtype).itemsize, dtype=dtype)
+        _check(lib.spmvHipMemcpyDown(_ptr(out), self.ptr, self.nbytes), "spmvHipMemcpyDown")
+        return out
+
+    def free(self):
+        if self.ptr:
+            lib.spmvHipFree(self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class DeviceMatrix:
+    """A device handle (`spmat` whose `dev` is set) plus what keeps it alive."""
+
+    def __init__(self):
+        self.handle = spmat()
+        self.keep = []
+        self.rows = 0
+
+    def free(self):
+        if self.handle.dev:
+            lib.hipFreeSpmat(C.byref(self.handle))
+        for k in self.keep:
+            if hasattr(k, "free"):
+                k.free()
+        self.keep = []
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+def spMatCpyCSR(host: HostCSR) -> DeviceMatrix:
+    d = DeviceMatrix()
+    _check(lib.spMatCpyCSR(C.byref(host.struct), C.byref(d.handle)), "spMatCpyCSR")
+    d.rows = host.M
+    return d
+
+
+def spMatCpyELL(host: HostELL) -> DeviceMatrix:
+    d = DeviceMatrix()
+    _check(lib.spMatCpyELL(C.byref(host.struct), C.byref(d.handle)), "spMatCpyELL")
+    d.rows = host.rows
+    return d
+
+
+def spmv(launcher: str, dmat: DeviceMatrix, dx: DeviceVector, dy: DeviceVector, cfg: CONFIG = None):
+    """Run one of the five HIP launchers; raises on EXIT_FAILURE."""
+    fn = SPMV_LAUNCHERS[launcher]
+    _check(fn(C.byref(dmat.handle), dx.ptr, cfg if cfg is not None else CONFIG(), dy.ptr), launcher)
+
+
+def set_variant(launcher: str, variant: int):
+    _check(lib.spmvHipSetVariant(launcher.encode(), int(variant)), "spmvHipSetVariant")
+
+
+def last_launch():
+    g, b = spmvDim3(), spmvDim3()
+    lib.spmvHipLastLaunch(C.byref(g), C.byref(b))
+    return (g.x, g.y, g.z), (b.x, b.y, b.z)
+
+
+def partition_rows(IRP, n_parts):
+    IRP = np.ascontiguousarray(IRP, dtype=np.uint64)
+    bounds = np.zeros(n_parts + 1, dtype=np.uint64)
+    _check(lib.spmvHipPartitionRows(_ptr(IRP), IRP.size - 1, n_parts, _ptr(bounds)), "spmvHipPartitionRows")
+    return bounds

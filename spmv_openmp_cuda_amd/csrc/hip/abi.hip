@@ -1,0 +1,592 @@
+// abi.hip -- the extern "C" boundary of libspmvhip.so (declared in include/spmvHip.h).
+// Upload/free restate src/commons/cudaUtils.cu:20-98 + src/include/cudaUtils.h:70-78;
+// the launchers replace `f<<<grid,block>>>(dMat,dVect,Conf,dOutV)` of
+// src/main.cu:221-238 and test/SpMV_test.cu:103-146.
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cstring>
+#include <map>
+#include <vector>
+
+#include "spmvHip.h"
+#include "kernels.hpp"
+
+using namespace spmvhip;
+
+namespace {
+
+struct State {
+    bool        inited = false;
+    int         dev = 0;
+    hipStream_t stream = nullptr;
+    bool        sync = true;
+    int         variantRowsCSR = 1;     // 0 scalar, 1 LDS-stream SEQ
+    int         variantWarpCSR = 1;     // 0 wavefront-per-row, 1 adaptive LDS-stream VEC
+    int         variantRowsEllNT = 0;
+    bool        ellRowLens = true;
+    double      lastSeconds = 0;
+    spmvDim3    lastGrid{0, 0, 0}, lastBlock{0, 0, 0};
+    hipEvent_t  ev0 = nullptr, ev1 = nullptr;
+} S;
+
+#define ERR(...) do { fprintf(stderr, "\33[31m\33[1m\33[44mlibspmvhip: "); fprintf(stderr, __VA_ARGS__); fprintf(stderr, "\33[0m\n"); } while (0)
+
+bool ready(const char* who) {
+    if (S.inited) return true;
+    ERR("%s: spmvHipInit() has not been called", who);
+    return false;
+}
+
+DevMat* descOf(spmat* h, const char* who) {
+    if (!h || !h->dev || h->dev == SPMAT_TAG_ELL_TRANSPOSED) {
+        ERR("%s: not a device handle (upload with spMatCpyCSR/spMatCpyELL first)", who);
+        return nullptr;
+    }
+    DevMat* d = static_cast<DevMat*>(h->dev);
+    if (d->magic != 0x53504D56) { ERR("%s: corrupted device handle", who); return nullptr; }
+    return d;
+}
+
+// Row blocks for csr_stream_kernel: consecutive rows are packed while their nnz
+// fit STREAM_NNZ (and at most STREAM_MAX_ROWS rows); a row longer than that is
+// a block of its own.
+template <typename I>
+void buildRowBlocks(const I* IRP, uint64_t M, std::vector<uint32_t>& blk, uint32_t& nLong, uint64_t& maxRow) {
+    blk.clear();
+    nLong = 0;
+    maxRow = 0;
+    blk.reserve(M / 64 + 2);
+    uint64_t r = 0;
+    blk.push_back(0);
+    while (r < M) {
+        const uint64_t start = IRP[r];
+        uint64_t e = r;
+        while (e < M && (uint64_t)IRP[e + 1] - start <= (uint64_t)STREAM_NNZ && e - r < STREAM_MAX_ROWS) ++e;
+        if (e == r) { ++e; ++nLong; }       // single long row
+        r = e;
+        blk.push_back((uint32_t)r);
+    }
+    for (uint64_t i = 0; i < M; ++i) maxRow = std::max<uint64_t>(maxRow, (uint64_t)IRP[i + 1] - (uint64_t)IRP[i]);
+}
+
+int uploadRowBlocks(DevMat* d, const std::vector<uint32_t>& blk) {
+    d->nBlk = (uint32_t)blk.size() - 1;
+    HIP_TRY(hipMalloc(&d->blkRow, blk.size() * sizeof(uint32_t)));
+    HIP_TRY(hipMemcpy(d->blkRow, blk.data(), blk.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    return EXIT_SUCCESS;
+}
+
+void freeDesc(DevMat* d) {
+    if (!d) return;
+    if (d->owns) {
+        (void)hipFree(d->IRP); (void)hipFree(d->JA); (void)hipFree(d->AS); (void)hipFree(d->RL);
+    }
+    (void)hipFree(d->blkRow);
+    d->magic = 0;
+    delete d;
+}
+
+void publish(spmat* h, DevMat* d, ulong M, ulong N, ulong NZ, ulong maxRowNz) {
+    memset(h, 0, sizeof *h);
+    h->M = M; h->N = N; h->NZ = NZ; h->MAX_ROW_NZ = maxRowNz;
+    h->JA = reinterpret_cast<ulong*>(d->JA);
+    h->AS = d->AS;
+    h->IRP = reinterpret_cast<ulong*>(d->IRP);
+    h->RL = reinterpret_cast<ulong*>(d->RL);
+    h->pitchJA = h->pitchAS = d->pitch;
+    h->dev = d;
+}
+
+// timing bracket used by every launcher
+struct Launch {
+    bool timed;
+    Launch(dim3 grid, dim3 block) : timed(S.sync) {
+        S.lastGrid = {grid.x, grid.y, grid.z};
+        S.lastBlock = {block.x, block.y, block.z};
+        if (timed) (void)hipEventRecord(S.ev0, S.stream);
+    }
+    int finish(const char* who) {
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) { ERR("%s: launch failed: %s", who, hipGetErrorString(e)); return EXIT_FAILURE; }
+        if (!timed) return EXIT_SUCCESS;
+        (void)hipEventRecord(S.ev1, S.stream);
+        e = hipEventSynchronize(S.ev1);
+        if (e != hipSuccess) { ERR("%s: kernel failed: %s", who, hipGetErrorString(e)); return EXIT_FAILURE; }
+        float ms = 0;
+        (void)hipEventElapsedTime(&ms, S.ev0, S.ev1);
+        S.lastSeconds = ms * 1e-3;
+        return EXIT_SUCCESS;
+    }
+};
+
+unsigned blockThreads(const CONFIG& cfg, unsigned dflt, unsigned maxThreads) {
+    unsigned t = cfg.blockSize.x * std::max(1u, cfg.blockSize.y) * std::max(1u, cfg.blockSize.z);
+    if (cfg.blockSize.x == 0) return dflt;
+    if (t % WAVE != 0 || t > maxThreads) {
+        ERR("CONFIG.blockSize %ux%ux%u is not a multiple of the 64-lane wavefront (or exceeds %u): using %u",
+            cfg.blockSize.x, cfg.blockSize.y, cfg.blockSize.z, maxThreads, dflt);
+        return dflt;
+    }
+    return t;
+}
+
+template <typename T>
+int narrowUpload(T** dDst, const ulong* hSrc, size_t n, ulong limit, const char* what) {
+    std::vector<T> tmp(n);
+    for (size_t i = 0; i < n; ++i) {
+        if (hSrc[i] > limit) { ERR("%s[%zu] = %lu does not fit the device index width", what, i, hSrc[i]); return EXIT_FAILURE; }
+        tmp[i] = (T)hSrc[i];
+    }
+    HIP_TRY(hipMalloc(dDst, std::max<size_t>(n, 1) * sizeof(T)));
+    HIP_TRY(hipMemcpy(*dDst, tmp.data(), n * sizeof(T), hipMemcpyHostToDevice));
+    return EXIT_SUCCESS;
+}
+
+__global__ void fill64_kernel(uint64_t* p, size_t n, uint64_t v) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) p[i] = v;
+}
+
+template <bool SEQ>
+static void launchStream(DevMat* d, double* x, double* y) {
+    if (d->irpBytes == 4)
+        hipLaunchKernelGGL((csr_stream_kernel<uint32_t, SEQ>), dim3(d->nBlk), dim3(WG_THREADS), 0, S.stream,
+                           d->blkRow, static_cast<const uint32_t*>(d->IRP), d->JA, d->AS, x, y);
+    else
+        hipLaunchKernelGGL((csr_stream_kernel<uint64_t, SEQ>), dim3(d->nBlk), dim3(WG_THREADS), 0, S.stream,
+                           d->blkRow, static_cast<const uint64_t*>(d->IRP), d->JA, d->AS, x, y);
+}
+
+
+template <int G>
+static void launchEllGroup(DevMat* d, bool rl, dim3 grid, dim3 block, double* x, double* y) {
+    if (rl) hipLaunchKernelGGL((ell_rowmajor_group<true, G>), grid, block, 0, S.stream, (uint32_t)d->M, (uint32_t)d->K, d->pitch, d->JA, d->AS, d->RL, x, y);
+    else    hipLaunchKernelGGL((ell_rowmajor_group<false, G>), grid, block, 0, S.stream, (uint32_t)d->M, (uint32_t)d->K, d->pitch, d->JA, d->AS, d->RL, x, y);
+}
+
+
+}  // namespace
+
+// Upload an (nRows x nCols) row-major host array pair with a padded pitch.
+static int uploadPitched(DevMat* d, const ulong* hJA, const double* hAS, size_t nRows, size_t nCols,
+                         size_t pitch, ulong colLimit) {
+    const size_t total = std::max<size_t>(nRows * pitch, 1);
+    std::vector<uint32_t> ja(total, 0u);
+    std::vector<double>   as(total, 0.0);
+    for (size_t r = 0; r < nRows; ++r)
+        for (size_t c = 0; c < nCols; ++c) {
+            const ulong col = hJA[r * nCols + c];
+            if (col > colLimit) { ERR("spMatCpyELL: column id %lu out of range", col); return EXIT_FAILURE; }
+            ja[r * pitch + c] = (uint32_t)col;
+            as[r * pitch + c] = hAS[r * nCols + c];
+        }
+    HIP_TRY(hipMalloc(&d->JA, total * sizeof(uint32_t)));
+    HIP_TRY(hipMalloc(&d->AS, total * sizeof(double)));
+    HIP_TRY(hipMemcpy(d->JA, ja.data(), total * sizeof(uint32_t), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(d->AS, as.data(), total * sizeof(double), hipMemcpyHostToDevice));
+    d->pitch = pitch;
+    return EXIT_SUCCESS;
+}
+
+static int ellUpload(spmat* m, spmat* dst, bool transposed) {
+    if (!ready("spMatCpyELL") || !m || !dst) return EXIT_FAILURE;
+    if (!m->JA || !m->AS) { ERR("spMatCpyELL: host matrix has no ELL arrays"); return EXIT_FAILURE; }
+    // reference field convention: a transposed matrix keeps slots in M and rows in MAX_ROW_NZ / N
+    const ulong rows  = transposed ? m->MAX_ROW_NZ : m->M;
+    const ulong slots = transposed ? m->M : m->MAX_ROW_NZ;
+    const ulong cols  = transposed ? 0 : m->N;      // column count is not recoverable from a transposed struct
+    if (rows >= (1ull << 32) - 1 || slots >= (1ull << 32) - 1) { ERR("spMatCpyELL: dimensions exceed 32-bit ids"); return EXIT_FAILURE; }
+    DevMat* d = new DevMat;
+    d->kind = transposed ? Kind::ELL_COLMAJOR : Kind::ELL_ROWMAJOR;
+    d->M = rows; d->N = cols; d->NZ = m->NZ; d->K = slots;
+    int rc;
+    const ulong colLimit = transposed ? 0xFFFFFFFFul : (m->N ? m->N - 1 : 0);
+    if (transposed) rc = uploadPitched(d, m->JA, m->AS, slots, rows, (rows + 63) / 64 * 64, colLimit);
+    else            rc = uploadPitched(d, m->JA, m->AS, rows, slots, (slots + 15) / 16 * 16, colLimit);
+    if (!rc && m->RL) rc = narrowUpload<uint32_t>(&d->RL, m->RL, rows, slots, "RL");
+    if (rc) { freeDesc(d); return EXIT_FAILURE; }
+    publish(dst, d, m->M, m->N, m->NZ, m->MAX_ROW_NZ);
+    return EXIT_SUCCESS;
+}
+
+namespace {
+struct Cached { spmat handle; double* dx = nullptr; double* dy = nullptr; int kind = 0; };
+std::map<const spmat*, Cached> g_cache;
+
+int hostCall(spmat* mat, double* x, CONFIG* cfg, double* y, int kind, SPMV_HIP_INTERF fn) {
+    if (!ready("spmvHip*")) return EXIT_FAILURE;
+    auto it = g_cache.find(mat);
+    if (it == g_cache.end() || it->second.kind != kind) {
+        if (it != g_cache.end()) { hipFreeSpmat(&it->second.handle); (void)hipFree(it->second.dx); (void)hipFree(it->second.dy); g_cache.erase(it); }
+        Cached c; c.kind = kind;
+        int rc;
+        ulong rows = mat->M, cols = mat->N;
+        if (kind == 0) rc = spMatCpyCSR(mat, &c.handle);
+        else if (kind == 1) rc = spMatCpyELL(mat, &c.handle);
+        else {  // column-major ELL: transposition is done on the fly from the row-major host matrix
+            spmat t = *mat;
+            std::vector<ulong> ja(mat->M * mat->MAX_ROW_NZ);
+            std::vector<double> as(mat->M * mat->MAX_ROW_NZ);
+            for (ulong r = 0; r < mat->M; ++r)
+                for (ulong c2 = 0; c2 < mat->MAX_ROW_NZ; ++c2) {
+                    ja[c2 * mat->M + r] = mat->JA[r * mat->MAX_ROW_NZ + c2];
+                    as[c2 * mat->M + r] = mat->AS[r * mat->MAX_ROW_NZ + c2];
+                }
+            t.JA = ja.data(); t.AS = as.data();
+            t.M = mat->MAX_ROW_NZ; t.N = mat->M; t.MAX_ROW_NZ = mat->M;
+            rc = spMatCpyELLTransposed(&t, &c.handle);
+        }
+        if (rc) return EXIT_FAILURE;
+        if (spmvHipVecAlloc(&c.dx, cols) || spmvHipVecAlloc(&c.dy, rows)) return EXIT_FAILURE;
+        it = g_cache.emplace(mat, c).first;
+    }
+    Cached& c = it->second;
+    const bool wasSync = S.sync;
+    S.sync = true;
+    int rc = spmvHipVecUp(c.dx, x, mat->N);
+    if (!rc) rc = spmvHipVecFill(c.dy, mat->M, 0x7FF8DEADDEADDEADull);     // poison y
+    if (!rc) rc = fn(&c.handle, c.dx, cfg ? *cfg : CONFIG{}, c.dy);
+    if (!rc) rc = spmvHipVecDown(y, c.dy, mat->M);
+    S.sync = wasSync;
+    return rc;
+}
+}  // namespace
+
+
+extern "C" {
+
+// ------------------------------------------------------------------------ lifecycle
+int spmvHipDeviceCount(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return -1;
+    return n;
+}
+
+int spmvHipInit(int dev, size_t sizeofSpmat, size_t sizeofConfig) {
+    if (sizeofSpmat != sizeof(spmat) || sizeofConfig != sizeof(CONFIG)) {
+        ERR("spmvHipInit: layout mismatch: caller spmat/CONFIG = %zu/%zu bytes, library %zu/%zu "
+            "(compile the host with this repo's include/spmv_types.h)",
+            sizeofSpmat, sizeofConfig, sizeof(spmat), sizeof(CONFIG));
+        return EXIT_FAILURE;
+    }
+    int n = spmvHipDeviceCount();
+    if (n <= 0) { ERR("spmvHipInit: no HIP device visible -- this library has no CPU fallback"); return EXIT_FAILURE; }
+    if (dev < 0 || dev >= n) { ERR("spmvHipInit: device %d out of range [0,%d)", dev, n); return EXIT_FAILURE; }
+    HIP_TRY(hipSetDevice(dev));
+    if (!S.ev0) HIP_TRY(hipEventCreate(&S.ev0));
+    if (!S.ev1) HIP_TRY(hipEventCreate(&S.ev1));
+    S.dev = dev;
+    S.inited = true;
+    return EXIT_SUCCESS;
+}
+
+int spmvHipFinalize(void) {
+    if (!S.inited) return EXIT_SUCCESS;
+    spmvHipDropCache();
+    if (S.ev0) (void)hipEventDestroy(S.ev0);
+    if (S.ev1) (void)hipEventDestroy(S.ev1);
+    S.ev0 = S.ev1 = nullptr;
+    S.inited = false;
+    return EXIT_SUCCESS;
+}
+
+int spmvHipSetStream(void* stream) { S.stream = static_cast<hipStream_t>(stream); return EXIT_SUCCESS; }
+int spmvHipSetSync(int sync) { S.sync = sync != 0; return EXIT_SUCCESS; }
+double spmvHipLastKernelSeconds(void) { return S.lastSeconds; }
+int spmvHipLastLaunch(spmvDim3* grid, spmvDim3* block) {
+    if (grid) *grid = S.lastGrid;
+    if (block) *block = S.lastBlock;
+    return EXIT_SUCCESS;
+}
+int spmvHipDeviceSynchronize(void) { HIP_TRY(hipDeviceSynchronize()); return EXIT_SUCCESS; }
+
+int spmvHipSetVariant(const char* launcher, int variant) {
+    if (!launcher) return EXIT_FAILURE;
+    if (!strcmp(launcher, "hipSpMVRowsCSR") && (variant == 0 || variant == 1)) { S.variantRowsCSR = variant; return EXIT_SUCCESS; }
+    if (!strcmp(launcher, "hipSpMVWarpPerRowCSR") && (variant == 0 || variant == 1)) { S.variantWarpCSR = variant; return EXIT_SUCCESS; }
+    ERR("spmvHipSetVariant: unknown (%s, %d)", launcher, variant);
+    return EXIT_FAILURE;
+}
+int spmvHipSetEllRowLens(int use) { S.ellRowLens = use != 0; return EXIT_SUCCESS; }
+
+// ------------------------------------------------------------------------ vectors
+int spmvHipVecAlloc(double** dVec, size_t n) {
+    if (!ready("spmvHipVecAlloc") || !dVec) return EXIT_FAILURE;
+    HIP_TRY(hipMalloc(dVec, std::max<size_t>(n, 1) * sizeof(double)));
+    return EXIT_SUCCESS;
+}
+int spmvHipVecFree(double* dVec) { HIP_TRY(hipFree(dVec)); return EXIT_SUCCESS; }
+int spmvHipVecUp(double* dVec, const double* hVec, size_t n) {
+    HIP_TRY(hipMemcpyAsync(dVec, hVec, n * sizeof(double), hipMemcpyHostToDevice, S.stream));
+    HIP_TRY(hipStreamSynchronize(S.stream));
+    return EXIT_SUCCESS;
+}
+int spmvHipVecDown(double* hVec, const double* dVec, size_t n) {
+    HIP_TRY(hipMemcpyAsync(hVec, dVec, n * sizeof(double), hipMemcpyDeviceToHost, S.stream));
+    HIP_TRY(hipStreamSynchronize(S.stream));
+    return EXIT_SUCCESS;
+}
+int spmvHipVecFill(double* dVec, size_t n, uint64_t pattern) {
+    if (n == 0) return EXIT_SUCCESS;
+    unsigned grid = (unsigned)std::min<size_t>((n + 255) / 256, 2048);
+    hipLaunchKernelGGL(fill64_kernel, dim3(grid), dim3(256), 0, S.stream, reinterpret_cast<uint64_t*>(dVec), n, pattern);
+    HIP_TRY(hipGetLastError());
+    if (S.sync) HIP_TRY(hipStreamSynchronize(S.stream));
+    return EXIT_SUCCESS;
+}
+
+int spmvHipMalloc(void** dPtr, size_t bytes) {
+    if (!ready("spmvHipMalloc") || !dPtr) return EXIT_FAILURE;
+    HIP_TRY(hipMalloc(dPtr, std::max<size_t>(bytes, 1)));
+    return EXIT_SUCCESS;
+}
+int spmvHipFree(void* dPtr) { HIP_TRY(hipFree(dPtr)); return EXIT_SUCCESS; }
+int spmvHipMemcpyUp(void* dDst, const void* hSrc, size_t bytes) {
+    HIP_TRY(hipMemcpyAsync(dDst, hSrc, bytes, hipMemcpyHostToDevice, S.stream));
+    HIP_TRY(hipStreamSynchronize(S.stream));
+    return EXIT_SUCCESS;
+}
+int spmvHipMemcpyDown(void* hDst, const void* dSrc, size_t bytes) {
+    HIP_TRY(hipMemcpyAsync(hDst, dSrc, bytes, hipMemcpyDeviceToHost, S.stream));
+    HIP_TRY(hipStreamSynchronize(S.stream));
+    return EXIT_SUCCESS;
+}
+
+// ------------------------------------------------------------------------ upload
+int spMatCpyCSR(spmat* m, spmat* dst) {
+    if (!ready("spMatCpyCSR") || !m || !dst) return EXIT_FAILURE;
+    if (!m->IRP || (m->NZ && (!m->JA || !m->AS))) { ERR("spMatCpyCSR: host matrix has no CSR arrays"); return EXIT_FAILURE; }
+    if (m->M >= (1ull << 32) - 1 || m->N > (1ull << 32)) { ERR("spMatCpyCSR: %lu x %lu exceeds the 32-bit row/column ids of the device format", m->M, m->N); return EXIT_FAILURE; }
+    if (m->IRP[0] != 0 || m->IRP[m->M] != m->NZ) { ERR("spMatCpyCSR: inconsistent row pointers (IRP[0]=%lu IRP[M]=%lu NZ=%lu)", m->IRP[0], m->IRP[m->M], m->NZ); return EXIT_FAILURE; }
+    DevMat* d = new DevMat;
+    d->kind = Kind::CSR;
+    d->M = m->M; d->N = m->N; d->NZ = m->NZ;
+    d->irpBytes = m->NZ < IRP32_LIMIT ? 4 : 8;
+    int rc = EXIT_SUCCESS;
+    if (d->irpBytes == 4) rc = narrowUpload<uint32_t>(reinterpret_cast<uint32_t**>(&d->IRP), m->IRP, m->M + 1, 0xFFFFFFFFul, "IRP");
+    else                  rc = narrowUpload<uint64_t>(reinterpret_cast<uint64_t**>(&d->IRP), m->IRP, m->M + 1, ~0ul, "IRP");
+    if (!rc) rc = narrowUpload<uint32_t>(&d->JA, m->JA, m->NZ, m->N ? m->N - 1 : 0, "JA");
+    if (!rc) {
+        if (!hipOk(hipMalloc(&d->AS, std::max<size_t>(m->NZ, 1) * sizeof(double)), "hipMalloc AS") ||
+            !hipOk(hipMemcpy(d->AS, m->AS, m->NZ * sizeof(double), hipMemcpyHostToDevice), "hipMemcpy AS")) rc = EXIT_FAILURE;
+    }
+    if (!rc && m->RL) rc = narrowUpload<uint32_t>(&d->RL, m->RL, m->M, 0xFFFFFFFFul, "RL");
+    if (!rc) {
+        std::vector<uint32_t> blk;
+        buildRowBlocks(m->IRP, m->M, blk, d->nLongBlk, d->maxRowNnz);
+        rc = uploadRowBlocks(d, blk);
+    }
+    if (rc) { freeDesc(d); return EXIT_FAILURE; }
+    publish(dst, d, m->M, m->N, m->NZ, 0);
+    return EXIT_SUCCESS;
+}
+
+int spmvHipAdoptCSR(spmat* dst, ulong M, ulong N, ulong NZ, const void* dIRP, int irpBytes,
+                    const uint32_t* dJA, const double* dAS, const void* hIRP) {
+    if (!ready("spmvHipAdoptCSR") || !dst || !dIRP) return EXIT_FAILURE;
+    if (irpBytes != 4 && irpBytes != 8) { ERR("spmvHipAdoptCSR: irpBytes must be 4 or 8"); return EXIT_FAILURE; }
+    if (irpBytes == 4 && NZ >= IRP32_LIMIT) { ERR("spmvHipAdoptCSR: NZ=%lu needs 64-bit row pointers", NZ); return EXIT_FAILURE; }
+    if (M >= (1ull << 32) - 1 || N > (1ull << 32)) { ERR("spmvHipAdoptCSR: dimensions exceed 32-bit ids"); return EXIT_FAILURE; }
+    std::vector<unsigned char> tmp;
+    if (!hIRP) {
+        tmp.resize((M + 1) * (size_t)irpBytes);
+        HIP_TRY(hipMemcpy(tmp.data(), dIRP, tmp.size(), hipMemcpyDeviceToHost));
+        hIRP = tmp.data();
+    }
+    DevMat* d = new DevMat;
+    d->kind = Kind::CSR; d->owns = false;
+    d->M = M; d->N = N; d->NZ = NZ; d->irpBytes = irpBytes;
+    d->IRP = const_cast<void*>(dIRP); d->JA = const_cast<uint32_t*>(dJA); d->AS = const_cast<double*>(dAS);
+    std::vector<uint32_t> blk;
+    if (irpBytes == 4) buildRowBlocks(static_cast<const uint32_t*>(hIRP), M, blk, d->nLongBlk, d->maxRowNnz);
+    else               buildRowBlocks(static_cast<const uint64_t*>(hIRP), M, blk, d->nLongBlk, d->maxRowNnz);
+    if (uploadRowBlocks(d, blk)) { freeDesc(d); return EXIT_FAILURE; }
+    publish(dst, d, M, N, NZ, 0);
+    return EXIT_SUCCESS;
+}
+
+int spMatCpyELL(spmat* m, spmat* dst) { return ellUpload(m, dst, m && m->dev == SPMAT_TAG_ELL_TRANSPOSED); }
+int spMatCpyELLTransposed(spmat* m, spmat* dst) { return ellUpload(m, dst, true); }
+
+int hipFreeSpmat(spmat* h) {
+    if (!h || !h->dev) return EXIT_SUCCESS;
+    DevMat* d = descOf(h, "hipFreeSpmat");
+    if (!d) return EXIT_FAILURE;
+    freeDesc(d);
+    memset(h, 0, sizeof *h);
+    return EXIT_SUCCESS;
+}
+
+// ------------------------------------------------------------------------ launchers
+int hipSpMVRowsCSR(spmat* dMat, double* dX, CONFIG cfg, double* dY) {
+    DevMat* d = descOf(dMat, "hipSpMVRowsCSR");
+    if (!d) return EXIT_FAILURE;
+    if (d->kind != Kind::CSR) { ERR("hipSpMVRowsCSR: handle is not CSR"); return EXIT_FAILURE; }
+    if (d->M == 0) return EXIT_SUCCESS;
+    if (S.variantRowsCSR == 0) {
+        const unsigned bt = blockThreads(cfg, BLOCKS_1D, 1024);
+        const dim3 grid((unsigned)((d->M + bt - 1) / bt)), block(bt);
+        Launch L(grid, block);
+        const uint32_t M = (uint32_t)d->M;
+        if (d->irpBytes == 4) hipLaunchKernelGGL((csr_scalar_kernel<uint32_t>), grid, block, 0, S.stream, M, static_cast<const uint32_t*>(d->IRP), d->JA, d->AS, dX, dY);
+        else                  hipLaunchKernelGGL((csr_scalar_kernel<uint64_t>), grid, block, 0, S.stream, M, static_cast<const uint64_t*>(d->IRP), d->JA, d->AS, dX, dY);
+        return L.finish("hipSpMVRowsCSR");
+    }
+    Launch L(dim3(d->nBlk), dim3(WG_THREADS));
+    launchStream<true>(d, dX, dY);
+    return L.finish("hipSpMVRowsCSR");
+}
+
+int hipSpMVWarpPerRowCSR(spmat* dMat, double* dX, CONFIG cfg, double* dY) {
+    DevMat* d = descOf(dMat, "hipSpMVWarpPerRowCSR");
+    if (!d) return EXIT_FAILURE;
+    if (d->kind != Kind::CSR) { ERR("hipSpMVWarpPerRowCSR: handle is not CSR"); return EXIT_FAILURE; }
+    if (d->M == 0) return EXIT_SUCCESS;
+    if (S.variantWarpCSR == 0) {
+        const unsigned bt = blockThreads(cfg, WAVESIZE * BLOCKS_2D_WARP_R, 1024);
+        const unsigned rowsPerWg = bt / WAVE;
+        const dim3 grid((unsigned)((d->M + rowsPerWg - 1) / rowsPerWg)), block(bt);
+        Launch L(grid, block);
+        const uint32_t M = (uint32_t)d->M;
+        if (d->irpBytes == 4) hipLaunchKernelGGL((csr_vector_kernel<uint32_t>), grid, block, 0, S.stream, M, static_cast<const uint32_t*>(d->IRP), d->JA, d->AS, dX, dY);
+        else                  hipLaunchKernelGGL((csr_vector_kernel<uint64_t>), grid, block, 0, S.stream, M, static_cast<const uint64_t*>(d->IRP), d->JA, d->AS, dX, dY);
+        return L.finish("hipSpMVWarpPerRowCSR");
+    }
+    Launch L(dim3(d->nBlk), dim3(WG_THREADS));
+    launchStream<false>(d, dX, dY);
+    return L.finish("hipSpMVWarpPerRowCSR");
+}
+
+int hipSpMVRowsELL(spmat* dMat, double* dX, CONFIG cfg, double* dY) {
+    DevMat* d = descOf(dMat, "hipSpMVRowsELL");
+    if (!d) return EXIT_FAILURE;
+    if (d->kind != Kind::ELL_COLMAJOR) { ERR("hipSpMVRowsELL: expects the transposed (column-major) ELL upload: ellTranspose() + spMatCpyELL()"); return EXIT_FAILURE; }
+    if (d->M == 0) return EXIT_SUCCESS;
+    const unsigned bt = blockThreads(cfg, BLOCKS_1D, 1024);
+    const dim3 grid((unsigned)((d->M + bt - 1) / bt)), block(bt);
+    Launch L(grid, block);
+    const bool rl = S.ellRowLens && d->RL;
+    if (rl) hipLaunchKernelGGL((ell_colmajor_thread<true>), grid, block, 0, S.stream, (uint32_t)d->M, (uint32_t)d->K, d->pitch, d->JA, d->AS, d->RL, dX, dY);
+    else    hipLaunchKernelGGL((ell_colmajor_thread<false>), grid, block, 0, S.stream, (uint32_t)d->M, (uint32_t)d->K, d->pitch, d->JA, d->AS, d->RL, dX, dY);
+    return L.finish("hipSpMVRowsELL");
+}
+
+int hipSpMVRowsELLNNTransposed(spmat* dMat, double* dX, CONFIG cfg, double* dY) {
+    DevMat* d = descOf(dMat, "hipSpMVRowsELLNNTransposed");
+    if (!d) return EXIT_FAILURE;
+    if (d->kind != Kind::ELL_ROWMAJOR) { ERR("hipSpMVRowsELLNNTransposed: expects the row-major ELL upload (no ellTranspose)"); return EXIT_FAILURE; }
+    if (d->M == 0) return EXIT_SUCCESS;
+    const unsigned bt = blockThreads(cfg, BLOCKS_1D, 1024);
+    const dim3 grid((unsigned)((d->M + bt - 1) / bt)), block(bt);
+    Launch L(grid, block);
+    const bool rl = S.ellRowLens && d->RL;
+    if (rl) hipLaunchKernelGGL((ell_rowmajor_thread<true>), grid, block, 0, S.stream, (uint32_t)d->M, (uint32_t)d->K, d->pitch, d->JA, d->AS, d->RL, dX, dY);
+    else    hipLaunchKernelGGL((ell_rowmajor_thread<false>), grid, block, 0, S.stream, (uint32_t)d->M, (uint32_t)d->K, d->pitch, d->JA, d->AS, d->RL, dX, dY);
+    return L.finish("hipSpMVRowsELLNNTransposed");
+}
+
+int hipSpMVWarpsPerRowELLNTrasposed(spmat* dMat, double* dX, CONFIG cfg, double* dY) {
+    DevMat* d = descOf(dMat, "hipSpMVWarpsPerRowELLNTrasposed");
+    if (!d) return EXIT_FAILURE;
+    if (d->kind != Kind::ELL_ROWMAJOR) { ERR("hipSpMVWarpsPerRowELLNTrasposed: expects the row-major ELL upload (no ellTranspose)"); return EXIT_FAILURE; }
+    if (d->M == 0) return EXIT_SUCCESS;
+    // lanes per row: the smallest power of two covering the slots, 4..64
+    int G = 4;
+    while (G < WAVE && (uint64_t)G < d->K) G <<= 1;
+    const unsigned bt = WG_THREADS;
+    (void)cfg;
+    const uint64_t threads = d->M * (uint64_t)G;
+    const dim3 grid((unsigned)((threads + bt - 1) / bt)), block(bt);
+    Launch L(grid, block);
+    const bool rl = S.ellRowLens && d->RL;
+    switch (G) {
+        case 4:  launchEllGroup<4>(d, rl, grid, block, dX, dY); break;
+        case 8:  launchEllGroup<8>(d, rl, grid, block, dX, dY); break;
+        case 16: launchEllGroup<16>(d, rl, grid, block, dX, dY); break;
+        case 32: launchEllGroup<32>(d, rl, grid, block, dX, dY); break;
+        default: launchEllGroup<64>(d, rl, grid, block, dX, dY); break;
+    }
+    return L.finish("hipSpMVWarpsPerRowELLNTrasposed");
+}
+
+// ------------------------------------------------------------------------ events
+int spmvHipEventCreate(void** ev) {
+    hipEvent_t e;
+    HIP_TRY(hipEventCreate(&e));
+    *ev = e;
+    return EXIT_SUCCESS;
+}
+int spmvHipEventDestroy(void* ev) { HIP_TRY(hipEventDestroy(static_cast<hipEvent_t>(ev))); return EXIT_SUCCESS; }
+int spmvHipEventRecord(void* ev) { HIP_TRY(hipEventRecord(static_cast<hipEvent_t>(ev), S.stream)); return EXIT_SUCCESS; }
+int spmvHipEventElapsedMs(void* a, void* b, float* ms) {
+    HIP_TRY(hipEventSynchronize(static_cast<hipEvent_t>(b)));
+    HIP_TRY(hipEventElapsedTime(ms, static_cast<hipEvent_t>(a), static_cast<hipEvent_t>(b)));
+    return EXIT_SUCCESS;
+}
+
+// ------------------------------------------------------------------------ SPMV_INTERF wrappers
+int spmvHipRowsCSR(spmat* mat, double* x, CONFIG* cfg, double* y) { return hostCall(mat, x, cfg, y, 0, &hipSpMVRowsCSR); }
+int spmvHipWarpPerRowCSR(spmat* mat, double* x, CONFIG* cfg, double* y) { return hostCall(mat, x, cfg, y, 0, &hipSpMVWarpPerRowCSR); }
+int spmvHipRowsELL(spmat* mat, double* x, CONFIG* cfg, double* y) { return hostCall(mat, x, cfg, y, 2, &hipSpMVRowsELL); }
+int spmvHipWarpsPerRowELL(spmat* mat, double* x, CONFIG* cfg, double* y) { return hostCall(mat, x, cfg, y, 1, &hipSpMVWarpsPerRowELLNTrasposed); }
+int spmvHipDropCache(void) {
+    for (auto& kv : g_cache) { hipFreeSpmat(&kv.second.handle); (void)hipFree(kv.second.dx); (void)hipFree(kv.second.dy); }
+    g_cache.clear();
+    return EXIT_SUCCESS;
+}
+
+// ------------------------------------------------------------------------ sharding helpers (host side)
+int spmvHipPartitionRows(const ulong* IRP, ulong M, int nParts, ulong* bounds) {
+    if (!IRP || !bounds || nParts <= 0) return EXIT_FAILURE;
+    const ulong nnz = IRP[M] - IRP[0];
+    bounds[0] = 0;
+    for (int p = 1; p < nParts; ++p) {
+        // first row whose starting offset reaches p/nParts of the nnz
+        const ulong target = IRP[0] + (ulong)(((__uint128_t)nnz * (unsigned)p) / (unsigned)nParts);
+        const ulong* it = std::lower_bound(IRP, IRP + M + 1, target);
+        ulong r = (ulong)(it - IRP);
+        if (r > M) r = M;
+        // choose the closer of r-1 / r
+        if (r > 0 && target - IRP[r - 1] < IRP[r] - target) --r;
+        bounds[p] = std::max(r, bounds[p - 1]);
+    }
+    bounds[nParts] = M;
+    return EXIT_SUCCESS;
+}
+
+int spmvHipCompactRows(double* dY, const double* dYPad, const ulong* bounds, int nParts, ulong maxRows) {
+    if (!dY || !dYPad || !bounds || nParts <= 0) return EXIT_FAILURE;
+    for (int p = 0; p < nParts; ++p) {
+        const ulong rows = bounds[p + 1] - bounds[p];
+        if (rows > maxRows) { ERR("spmvHipCompactRows: block %d has %lu rows > pad %lu", p, rows, maxRows); return EXIT_FAILURE; }
+        if (rows)
+            HIP_TRY(hipMemcpyAsync(dY + bounds[p], dYPad + (size_t)p * maxRows, rows * sizeof(double),
+                                   hipMemcpyDeviceToDevice, S.stream));
+    }
+    if (S.sync) HIP_TRY(hipStreamSynchronize(S.stream));
+    return EXIT_SUCCESS;
+}
+
+spmat* spmvHipRowBlockCSR(const spmat* host, ulong r0, ulong r1) {
+    if (!host || !host->IRP || r0 > r1 || r1 > host->M) return nullptr;
+    spmat* out = static_cast<spmat*>(calloc(1, sizeof(spmat)));
+    if (!out) return nullptr;
+    const ulong base = host->IRP[r0], nz = host->IRP[r1] - base, rows = r1 - r0;
+    out->M = rows; out->N = host->N; out->NZ = nz;
+    out->IRP = static_cast<ulong*>(malloc((rows + 1) * sizeof(ulong)));
+    out->JA  = static_cast<ulong*>(malloc(std::max<ulong>(nz, 1) * sizeof(ulong)));
+    out->AS  = static_cast<double*>(malloc(std::max<ulong>(nz, 1) * sizeof(double)));
+    if (host->RL) out->RL = static_cast<ulong*>(malloc(std::max<ulong>(rows, 1) * sizeof(ulong)));
+    if (!out->IRP || !out->JA || !out->AS || (host->RL && !out->RL)) {
+        free(out->IRP); free(out->JA); free(out->AS); free(out->RL); free(out);
+        return nullptr;
+    }
+    for (ulong r = 0; r <= rows; ++r) out->IRP[r] = host->IRP[r0 + r] - base;
+    memcpy(out->JA, host->JA + base, nz * sizeof(ulong));
+    memcpy(out->AS, host->AS + base, nz * sizeof(double));
+    if (host->RL) memcpy(out->RL, host->RL + r0, rows * sizeof(ulong));
+    return out;
+}
+
+}  // extern "C"

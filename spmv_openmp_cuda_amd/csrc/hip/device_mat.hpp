@@ -1,0 +1,54 @@
+// device_mat.hpp -- the library-private descriptor behind a device `spmat` handle.
+//
+// HBM layout (see DESIGN.md "Data layout in HBM"):
+//   AS   fp64 values
+//   JA   32-bit column ids (host keeps 64-bit `ulong`; narrowed during upload)
+//   IRP  32-bit row pointers when NZ < 2^32, else 64-bit
+//   RL   32-bit row lengths (optional)
+//   ELL  row-major  [rows ][pitch(slots)]  pitch = slots rounded up to 16 elements
+//        col-major  [slots][pitch(rows )]  pitch = rows  rounded up to 64 elements
+//   blkRow  row-block boundaries of the LDS-stream kernel (CSR only)
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+
+namespace spmvhip {
+
+constexpr int      WAVE            = 64;
+constexpr int      WG_THREADS      = 256;      // 4 wavefronts
+constexpr int      STREAM_NNZ      = 2048;     // nnz staged in LDS per workgroup (16 KiB of fp64)
+constexpr uint32_t STREAM_MAX_ROWS = 2048;     // bounds a block made of empty / 1-nnz rows
+// 32-bit row pointers are used only below this nnz count, so that `j + stride`
+// in the kernels can never wrap around 2^32
+constexpr uint64_t IRP32_LIMIT     = (1ull << 32) - 65536;
+
+enum class Kind : int { CSR = 0, ELL_ROWMAJOR = 1, ELL_COLMAJOR = 2 };
+
+struct DevMat {
+    uint32_t magic = 0x53504D56;    // 'SPMV'
+    Kind     kind  = Kind::CSR;
+    uint64_t M = 0, N = 0, NZ = 0;  // logical rows, cols, true nnz
+    uint64_t K = 0;                 // ELL slots per row (max row nnz)
+    int      irpBytes = 4;
+    void*     IRP = nullptr;
+    uint32_t* JA  = nullptr;
+    double*   AS  = nullptr;
+    uint32_t* RL  = nullptr;
+    size_t    pitch = 0;            // ELL pitch in elements (same for JA and AS)
+    bool      owns = true;          // false for adopted arrays
+    // row blocks (CSR): block b covers rows [blkRow[b], blkRow[b+1])
+    uint32_t* blkRow = nullptr;
+    uint32_t  nBlk = 0;
+    uint32_t  nLongBlk = 0;         // blocks that are a single row longer than STREAM_NNZ
+    uint64_t  maxRowNnz = 0;
+};
+
+inline bool hipOk(hipError_t e, const char* what) {
+    if (e == hipSuccess) return true;
+    fprintf(stderr, "\33[31m\33[1m\33[44mlibspmvhip: %s\t%s\33[0m\n", what, hipGetErrorString(e));
+    return false;
+}
+#define HIP_TRY(expr) do { if (!::spmvhip::hipOk((expr), #expr)) return EXIT_FAILURE; } while (0)
+
+}  // namespace spmvhip

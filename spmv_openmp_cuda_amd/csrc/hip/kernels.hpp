@@ -1,0 +1,246 @@
+// kernels.hpp -- hand-written gfx950 SpMV kernels (fp64 values, 32-bit column ids).
+//
+// What each kernel restates (reference paths relative to its root):
+//   csr_scalar_kernel      cudaSpMVRowsCSR                   src/SpMV_CUDA.cu:33-49
+//   csr_vector_kernel      cudaSpMVWarpPerRowCSR             src/SpMV_CUDA.cu:52-73   (as intended: every row)
+//   csr_stream_kernel      both of the above, MI355X-first: coalesced span load -> LDS -> per-row reduce
+//   ell_colmajor_thread    cudaSpMVRowsELL                   src/SpMV_CUDA.cu:79-96
+//   ell_rowmajor_thread    cudaSpMVRowsELLNNTransposed       src/SpMV_CUDA.cu:99-115
+//   ell_rowmajor_group     cudaSpMVWarpsPerRowELLNTrasposed  src/SpMV_CUDA.cu:116-135
+//   wave_sum               reduceWarpRegs                    src/include/cudaUtils.h:101-106 (32 lanes there, 64 here)
+//
+// All kernels take POD arguments by value (the reference passes a pointer to a
+// device-resident struct and re-reads m->M, m->IRP... from global memory in
+// every iteration, SpMV_CUDA.cu:35,44-45).
+//
+// The library is compiled with -ffp-contract=off: products are rounded before
+// they are added, so every kernel that adds a row's products in ascending-j
+// order is bit-identical to the serial oracle (sgemvSerial, gcc -O2 x86-64).
+#pragma once
+#include "device_mat.hpp"
+
+namespace spmvhip {
+
+// streamed-once data: keep it out of the way of x in L2 / Infinity Cache
+template <typename T>
+__device__ __forceinline__ T stream_load(const T* p) { return __builtin_nontemporal_load(p); }
+
+// sum over the 64 lanes of a wavefront; result valid in lane 0
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int off = WAVE / 2; off > 0; off >>= 1) v += __shfl_down(v, off, WAVE);
+    return v;
+}
+// sum over aligned groups of G lanes (G power of two <= 64); valid in the group's lane 0
+template <int G>
+__device__ __forceinline__ double group_sum(double v) {
+#pragma unroll
+    for (int off = G / 2; off > 0; off >>= 1) v += __shfl_down(v, off, G);
+    return v;
+}
+__device__ __forceinline__ double group_sum_rt(double v, int G) {
+    for (int off = G >> 1; off > 0; off >>= 1) v += __shfl_down(v, off, G);
+    return v;
+}
+
+// ----------------------------------------------------------------------------------- CSR
+// One thread walks one row directly in global memory.  Kept as the plain
+// restatement of the reference kernel (variant 0) and as the A/B baseline for
+// the LDS-stream kernel: lanes stride by the row length, so AS/JA reads are
+// uncoalesced.
+template <typename I>
+__global__ __launch_bounds__(WG_THREADS) void csr_scalar_kernel(
+    uint32_t M, const I* __restrict__ IRP, const uint32_t* __restrict__ JA,
+    const double* __restrict__ AS, const double* __restrict__ x, double* __restrict__ y) {
+    const uint32_t row = blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= M) return;
+    const I b = IRP[row], e = IRP[row + 1];
+    double acc = 0;
+    for (I j = b; j < e; ++j) acc += AS[j] * x[JA[j]];
+    y[row] = acc;
+}
+
+// One wavefront per row, lanes stride the row, shuffle tree, lane 0 stores.
+// rowsPerWg = blockDim.x / 64 wavefronts share a workgroup.
+template <typename I>
+__global__ __launch_bounds__(1024) void csr_vector_kernel(
+    uint32_t M, const I* __restrict__ IRP, const uint32_t* __restrict__ JA,
+    const double* __restrict__ AS, const double* __restrict__ x, double* __restrict__ y) {
+    const uint32_t wavesPerWg = blockDim.x / WAVE;
+    const uint32_t row  = blockIdx.x * wavesPerWg + threadIdx.x / WAVE;   // wave-uniform
+    const uint32_t lane = threadIdx.x % WAVE;
+    if (row >= M) return;
+    const I b = IRP[row], e = IRP[row + 1];
+    double acc = 0;
+    for (I j = b + lane; j < e; j += WAVE) acc += stream_load(AS + j) * x[stream_load(JA + j)];
+    acc = wave_sum(acc);
+    if (lane == 0) y[row] = acc;
+}
+
+// LDS-stream kernel.  Workgroup b owns the consecutive rows
+// [blkRow[b], blkRow[b+1]) whose nnz span is contiguous in AS/JA:
+//   1. every lane loads nnz tid, tid+256, ... of the span (fully coalesced,
+//      non-temporal), gathers x and parks the rounded product in LDS;
+//   2. the rows' segments of the LDS array are summed
+//        SEQ: one thread per row, ascending j  -> bit-identical to the oracle
+//        VEC: L lanes per row (L = largest power of two with L*rows <= 256),
+//             lane-strided partial sums + shuffle tree (LDS segmented reduction)
+// A block that is a single row longer than STREAM_NNZ takes the
+// workgroup-per-row path instead (lane-strided walk, wave shuffle, LDS combine).
+constexpr int STREAM_UNROLL = STREAM_NNZ / WG_THREADS;
+
+template <typename I, bool SEQ>
+__global__ __launch_bounds__(WG_THREADS) void csr_stream_kernel(
+    const uint32_t* __restrict__ blkRow, const I* __restrict__ IRP,
+    const uint32_t* __restrict__ JA, const double* __restrict__ AS,
+    const double* __restrict__ x, double* __restrict__ y) {
+    __shared__ double prod[STREAM_NNZ];
+    __shared__ double wpart[WG_THREADS / WAVE];
+
+    const uint32_t tid = threadIdx.x;
+    const uint32_t r0 = blkRow[blockIdx.x], r1 = blkRow[blockIdx.x + 1];
+    const I base = IRP[r0], end = IRP[r1];
+
+    if (end - base > (I)STREAM_NNZ) {
+        // ---- long row (the analysis guarantees r1 == r0 + 1): workgroup-per-row
+        double acc0 = 0, acc1 = 0, acc2 = 0, acc3 = 0;
+        I j = base + tid;
+        for (; j + 3 * WG_THREADS < end; j += 4 * WG_THREADS) {
+            const uint32_t c0 = stream_load(JA + j), c1 = stream_load(JA + j + WG_THREADS),
+                           c2 = stream_load(JA + j + 2 * WG_THREADS), c3 = stream_load(JA + j + 3 * WG_THREADS);
+            const double a0 = stream_load(AS + j), a1 = stream_load(AS + j + WG_THREADS),
+                         a2 = stream_load(AS + j + 2 * WG_THREADS), a3 = stream_load(AS + j + 3 * WG_THREADS);
+            acc0 += a0 * x[c0]; acc1 += a1 * x[c1]; acc2 += a2 * x[c2]; acc3 += a3 * x[c3];
+        }
+        for (; j < end; j += WG_THREADS) acc0 += stream_load(AS + j) * x[stream_load(JA + j)];
+        double acc = wave_sum((acc0 + acc1) + (acc2 + acc3));
+        if (tid % WAVE == 0) wpart[tid / WAVE] = acc;
+        __syncthreads();
+        if (tid == 0) {
+            double s = wpart[0];
+#pragma unroll
+            for (int w = 1; w < WG_THREADS / WAVE; ++w) s += wpart[w];
+            y[r0] = s;
+        }
+        return;
+    }
+
+    // ---- 1. coalesced span load, gather, products to LDS
+    const uint32_t n = (uint32_t)(end - base);
+    {
+        uint32_t col[STREAM_UNROLL];
+        double   val[STREAM_UNROLL];
+#pragma unroll
+        for (int u = 0; u < STREAM_UNROLL; ++u) {
+            const uint32_t k = tid + u * WG_THREADS;
+            const bool in = k < n;
+            col[u] = in ? stream_load(JA + base + k) : 0u;
+            val[u] = in ? stream_load(AS + base + k) : 0.0;
+        }
+        double xv[STREAM_UNROLL];
+#pragma unroll
+        for (int u = 0; u < STREAM_UNROLL; ++u) xv[u] = x[col[u]];
+#pragma unroll
+        for (int u = 0; u < STREAM_UNROLL; ++u) {
+            const uint32_t k = tid + u * WG_THREADS;
+            if (k < n) prod[k] = val[u] * xv[u];
+        }
+    }
+    __syncthreads();
+
+    // ---- 2. per-row reduction out of LDS
+    const uint32_t R = r1 - r0;
+    if (SEQ) {
+        for (uint32_t r = r0 + tid; r < r1; r += WG_THREADS) {
+            const uint32_t s = (uint32_t)(IRP[r] - base), e = (uint32_t)(IRP[r + 1] - base);
+            double acc = 0;
+            for (uint32_t j = s; j < e; ++j) acc += prod[j];
+            y[r] = acc;
+        }
+    } else {
+        int L = 1;
+        while (L < WAVE && 2u * L * R <= (uint32_t)WG_THREADS) L <<= 1;   // block-uniform
+        const uint32_t rowsPerPass = WG_THREADS / L;
+        const uint32_t g = tid / L, l = tid % L;
+        const uint32_t passes = (R + rowsPerPass - 1) / rowsPerPass;       // same trip count for every lane
+        for (uint32_t p = 0; p < passes; ++p) {
+            const uint32_t rr = p * rowsPerPass + g;
+            const bool live = rr < R;
+            uint32_t s = 0, e = 0;
+            if (live) {
+                s = (uint32_t)(IRP[r0 + rr] - base);
+                e = (uint32_t)(IRP[r0 + rr + 1] - base);
+            }
+            double acc = 0;
+            for (uint32_t j = s + l; j < e; j += L) acc += prod[j];
+            acc = group_sum_rt(acc, L);
+            if (live && l == 0) y[r0 + rr] = acc;
+        }
+    }
+}
+
+// ----------------------------------------------------------------------------------- ELL
+// Column-major ("transposed") + pitched, one thread per row: lane i of a wave
+// reads element i of a 512-byte line in every slot.  USE_RL = stop at the row's
+// own length; otherwise walk all slots incl. the {AS=0,JA=0} padding exactly
+// like the reference kernel does.
+template <bool USE_RL>
+__global__ __launch_bounds__(WG_THREADS) void ell_colmajor_thread(
+    uint32_t rows, uint32_t slots, size_t pitch, const uint32_t* __restrict__ JA,
+    const double* __restrict__ AS, const uint32_t* __restrict__ RL,
+    const double* __restrict__ x, double* __restrict__ y) {
+    const uint32_t row = blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= rows) return;
+    const uint32_t n = USE_RL ? RL[row] : slots;
+    double acc = 0;
+    size_t idx = row;
+    uint32_t i = 0;
+    for (; i + 4 <= n; i += 4, idx += 4 * pitch) {
+        const uint32_t c0 = stream_load(JA + idx), c1 = stream_load(JA + idx + pitch),
+                       c2 = stream_load(JA + idx + 2 * pitch), c3 = stream_load(JA + idx + 3 * pitch);
+        const double a0 = stream_load(AS + idx), a1 = stream_load(AS + idx + pitch),
+                     a2 = stream_load(AS + idx + 2 * pitch), a3 = stream_load(AS + idx + 3 * pitch);
+        const double x0 = x[c0], x1 = x[c1], x2 = x[c2], x3 = x[c3];
+        acc += a0 * x0; acc += a1 * x1; acc += a2 * x2; acc += a3 * x3;   // ascending slot order
+    }
+    for (; i < n; ++i, idx += pitch) acc += stream_load(AS + idx) * x[stream_load(JA + idx)];
+    y[row] = acc;
+}
+
+// Row-major + pitched, one thread per row (lane stride = pitch: uncoalesced by
+// construction -- the reference's slowest kernel, kept for the A/B).
+template <bool USE_RL>
+__global__ __launch_bounds__(WG_THREADS) void ell_rowmajor_thread(
+    uint32_t rows, uint32_t slots, size_t pitch, const uint32_t* __restrict__ JA,
+    const double* __restrict__ AS, const uint32_t* __restrict__ RL,
+    const double* __restrict__ x, double* __restrict__ y) {
+    const uint32_t row = blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= rows) return;
+    const uint32_t n = USE_RL ? RL[row] : slots;
+    const size_t p = (size_t)row * pitch;
+    double acc = 0;
+    for (uint32_t c = 0; c < n; ++c) acc += AS[p + c] * x[JA[p + c]];
+    y[row] = acc;
+}
+
+// Row-major + pitched, G lanes per row (G = 64 is the reference's
+// warp-per-row; smaller G packs 64/G short rows into one wavefront so lanes are
+// not idle when slots < 64).  Lanes stride the row, shuffle tree, group lane 0 stores.
+template <bool USE_RL, int G>
+__global__ __launch_bounds__(WG_THREADS) void ell_rowmajor_group(
+    uint32_t rows, uint32_t slots, size_t pitch, const uint32_t* __restrict__ JA,
+    const double* __restrict__ AS, const uint32_t* __restrict__ RL,
+    const double* __restrict__ x, double* __restrict__ y) {
+    const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t row = gid / G;
+    const uint32_t l = (uint32_t)(gid % G);
+    const bool live = row < rows;
+    const uint32_t n = live ? (USE_RL ? RL[row] : slots) : 0u;
+    const size_t p = (size_t)row * pitch;
+    double acc = 0;
+    for (uint32_t c = l; c < n; c += G) acc += stream_load(AS + p + c) * x[stream_load(JA + p + c)];
+    acc = group_sum<G>(acc);
+    if (live && l == 0) y[row] = acc;
+}
+
+}  // namespace spmvhip

@@ -1,0 +1,163 @@
+"""GPU parity: every HIP launcher (through the C-ABI) against the serial oracle.
+
+Gate = the reference's own: |y_gpu - y_oracle| <= 7e-4 per element
+(src/include/config.h:113, src/commons/utils.c:362-393) with NaN = failure, y
+poisoned before every launch.  On top of it:
+  * kernels that add a row's products in ascending-j order must be BIT-IDENTICAL
+    to sgemvSerial (hipSpMVRowsCSR both variants, hipSpMVRowsELL,
+    hipSpMVRowsELLNNTransposed);
+  * shuffle-tree kernels must satisfy |dy| <= 1e-13 * sum|a_ij x_j|.
+"""
+import numpy as np
+import pytest
+
+from conftest import random_csr, tight_error
+
+pytestmark = pytest.mark.gpu
+
+GATE = 7e-4
+TIGHT = 1e-13
+
+
+@pytest.fixture(scope="module")
+def api():
+    from spmv_openmp_cuda_amd import api as a
+    a.spmvHipInit(0)
+    yield a
+    a.spmvHipFinalize()
+
+
+def _cases():
+    rng = np.random.default_rng(1234)
+    cases = {}
+    # irregular: empty rows, single entries, rows straddling the 2048-nnz block size, long rows
+    M, N = 3000, 5000
+    lens = rng.integers(0, 40, size=M)
+    lens[::7] = 0
+    lens[5] = 2048
+    lens[6] = 2049          # first row of the long-row path
+    lens[100] = 4999
+    lens[2999] = 3000
+    cases["irregular"] = (M, N) + random_csr(rng, M, N, lens)
+    # cage4-shaped: 9x9, 49 nnz, max row 6
+    lens = np.array([5, 6, 5, 6, 5, 6, 5, 6, 5])
+    cases["cage4-shaped"] = (9, 9) + random_csr(rng, 9, 9, lens)
+    # all-empty and single-row
+    cases["empty-rows"] = (70, 10) + random_csr(rng, 70, 10, np.zeros(70, dtype=int))
+    cases["one-long-row"] = (1, 20000) + random_csr(rng, 1, 20000, np.array([20000]))
+    # many 1-nnz rows (more than STREAM_MAX_ROWS per block)
+    cases["ones"] = (10000, 300) + random_csr(rng, 10000, 300, np.ones(10000, dtype=int))
+    # uniform 32/row
+    cases["uniform32"] = (4096, 4096) + random_csr(rng, 4096, 4096, np.full(4096, 32))
+    return cases
+
+
+CASES = _cases()
+
+
+def _x(rng, n):
+    return np.sin(rng.uniform(0, 2 * np.pi, size=n)) * 3e-5
+
+
+def _run(api, launcher, dmat, x, rows):
+    dx = api.DeviceVector(x.size).up(x)
+    dy = api.DeviceVector(rows)
+    dy.poison()
+    api.spmv(launcher, dmat, dx, dy)
+    y = dy.down()
+    dx.free()
+    dy.free()
+    return y
+
+
+@pytest.mark.parametrize("name", list(CASES))
+@pytest.mark.parametrize("launcher,variant,exact", [
+    ("hipSpMVRowsCSR", 0, True), ("hipSpMVRowsCSR", 1, True),
+    ("hipSpMVWarpPerRowCSR", 0, False), ("hipSpMVWarpPerRowCSR", 1, False)])
+def test_csr(api, oracle, name, launcher, variant, exact):
+    M, N, IRP, JA, AS = CASES[name]
+    x = _x(np.random.default_rng(7), N)
+    y_ref = oracle.csr_serial(IRP, JA, AS, x)
+    host = api.HostCSR(M, N, IRP, JA, AS)
+    dmat = api.spMatCpyCSR(host)
+    api.set_variant(launcher, variant)
+    y = _run(api, launcher, dmat, x, M)
+    dmat.free()
+    assert not np.isnan(y).any(), "rows left unwritten (poison survived)"
+    assert np.max(np.abs(y - y_ref), initial=0.0) <= GATE
+    if exact:
+        assert np.array_equal(y, y_ref)
+    else:
+        assert tight_error(IRP, JA, AS, x, y_ref, y) <= TIGHT
+
+
+@pytest.mark.parametrize("name", ["irregular", "cage4-shaped", "ones", "uniform32", "empty-rows"])
+@pytest.mark.parametrize("rowlens", [True, False])
+@pytest.mark.parametrize("launcher,transposed,exact", [
+    ("hipSpMVRowsELL", True, True),
+    ("hipSpMVRowsELLNNTransposed", False, True),
+    ("hipSpMVWarpsPerRowELLNTrasposed", False, False)])
+def test_ell(api, oracle, name, rowlens, launcher, transposed, exact):
+    M, N, IRP, JA, AS = CASES[name]
+    x = _x(np.random.default_rng(8), N)
+    y_ref = oracle.csr_serial(IRP, JA, AS, x)
+    ell = api.HostCSR(M, N, IRP, JA, AS).to_ell(with_row_lens=rowlens)
+    dmat = api.spMatCpyELL(ell.transpose() if transposed else ell)
+    api.lib.spmvHipSetEllRowLens(1 if rowlens else 0)
+    y = _run(api, launcher, dmat, x, M)
+    dmat.free()
+    api.lib.spmvHipSetEllRowLens(1)
+    assert not np.isnan(y).any()
+    assert np.max(np.abs(y - y_ref), initial=0.0) <= GATE
+    if exact:
+        # padding adds +0.0*x[0] terms: exact unless the row sum is -0.0
+        assert np.array_equal(y, y_ref + 0.0)
+    else:
+        assert tight_error(IRP, JA, AS, x, y_ref, y) <= TIGHT
+
+
+def test_wrong_handle_kind_fails_loudly(api):
+    M, N, IRP, JA, AS = CASES["cage4-shaped"]
+    host = api.HostCSR(M, N, IRP, JA, AS)
+    dmat = api.spMatCpyCSR(host)
+    dx, dy = api.DeviceVector(N), api.DeviceVector(M)
+    with pytest.raises(api.SpmvHipError):
+        api.spmv("hipSpMVRowsELL", dmat, dx, dy)
+    dmat.free()
+
+
+def test_synth_device_matches_twin_and_oracle(api, oracle):
+    """Device generator == CPU twin bit-for-bit; SpMV on it == oracle."""
+    from spmv_openmp_cuda_amd import synth
+    for key in ("tiny", "tinyu"):
+        for band in (0, 64):
+            w = synth.WORKLOADS[key]
+            w = synth.Workload(w.name, w.N, w.nnz, w.law, w.max_row, w.cfg, band)
+            lens = synth.row_lengths(w)
+            irp = synth.prefix(lens)
+            dm = synth.device_csr(w, irp, 0, w.N)
+            ja_dev = dm.buffers["JA"].down(np.uint32)
+            as_dev = dm.buffers["AS"].down(np.float64)
+            ja_ref, as_ref = oracle.synth_fill(w.N, 0, irp, synth.SEED_STRUCT + w.cfg, synth.SEED_VAL + w.cfg, band)
+            assert np.array_equal(ja_dev, ja_ref) and np.array_equal(as_dev, as_ref)
+            # columns ascending and distinct within each row, inside [0,N)
+            d = np.diff(ja_ref.astype(np.int64))
+            row_starts = irp[1:-1].astype(np.int64)
+            mask = np.ones(d.size, dtype=bool)
+            mask[row_starts[(row_starts > 0) & (row_starts < ja_ref.size)] - 1] = False
+            assert (d[mask] > 0).all() and ja_ref.max() < w.N
+            x = synth.make_x(w.N, w.cfg)
+            y_ref = oracle.csr_serial_dev(irp.astype(np.uint32), ja_ref, as_ref, x)
+            for launcher, exact in (("hipSpMVRowsCSR", True), ("hipSpMVWarpPerRowCSR", False)):
+                y = _run(api, launcher, dm, x, w.N)
+                assert np.max(np.abs(y - y_ref)) <= GATE
+                if exact:
+                    assert np.array_equal(y, y_ref)
+            # a shard generated with a row offset equals the same rows of the whole matrix
+            r0, r1 = w.N // 3, w.N // 3 + 1000
+            sh = synth.device_csr(w, irp, r0, r1)
+            b0, b1 = int(irp[r0]), int(irp[r1])
+            assert np.array_equal(sh.buffers["JA"].down(np.uint32), ja_ref[b0:b1])
+            assert np.array_equal(sh.buffers["AS"].down(np.float64), as_ref[b0:b1])
+            sh.free()
+            dm.free()
