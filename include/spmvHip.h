@@ -99,6 +99,11 @@ SPMV_HIP hipSpMVRowsELL;                  /* <- cudaSpMVRowsELL (transposed)    
 SPMV_HIP hipSpMVRowsELLNNTransposed;      /* <- cudaSpMVRowsELLNNTransposed      SpMV_CUDA.cu:99-115  */
 SPMV_HIP hipSpMVWarpsPerRowELLNTrasposed; /* <- cudaSpMVWarpsPerRowELLNTrasposed SpMV_CUDA.cu:116-135 */
 
+/* Enqueue-only form of the two CSR launchers on an explicit stream (no timing
+ * bracket, no synchronisation): warpPerRow = 0 -> hipSpMVRowsCSR semantics,
+ * != 0 -> hipSpMVWarpPerRowCSR.  The current device must be the matrix'. */
+int spmvHipEnqueueCSR(spmat* dMat, int warpPerRow, double* dX, double* dY, void* stream);
+
 /* Kernel variants behind each launcher (for A/B measurement; default = best):
  *   hipSpMVRowsCSR        0 = one thread walks its row in global memory ("scalar")
  *                         1 = LDS-stream: coalesced span load, one thread sums its row

@@ -419,6 +419,19 @@ int hipFreeSpmat(spmat* h) {
 }
 
 // ------------------------------------------------------------------------ launchers
+// enqueue-only entry used by shard.hip (explicit stream, no timing bracket, current device = the matrix')
+int spmvHipEnqueueCSR(spmat* dMat, int warpPerRow, double* dX, double* dY, void* stream) {
+    DevMat* d = descOf(dMat, "spmvHipEnqueueCSR");
+    if (!d || d->kind != Kind::CSR) return EXIT_FAILURE;
+    if (d->M == 0) return EXIT_SUCCESS;
+    hipStream_t keep = S.stream;
+    S.stream = static_cast<hipStream_t>(stream);
+    if (warpPerRow) launchStream<false>(d, dX, dY); else launchStream<true>(d, dX, dY);
+    S.stream = keep;
+    HIP_TRY(hipGetLastError());
+    return EXIT_SUCCESS;
+}
+
 int hipSpMVRowsCSR(spmat* dMat, double* dX, CONFIG cfg, double* dY) {
     DevMat* d = descOf(dMat, "hipSpMVRowsCSR");
     if (!d) return EXIT_FAILURE;

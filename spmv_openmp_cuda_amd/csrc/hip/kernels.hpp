@@ -102,17 +102,39 @@ __global__ __launch_bounds__(WG_THREADS) void csr_stream_kernel(
     const I base = IRP[r0], end = IRP[r1];
 
     if (end - base > (I)STREAM_NNZ) {
-        // ---- long row (the analysis guarantees r1 == r0 + 1): workgroup-per-row
+        // ---- long row (the analysis guarantees r1 == r0 + 1)
+        if (SEQ) {
+            // thread-per-row semantics: ONE accumulator, ascending j.  The row is
+            // still streamed coalesced, 2048 products at a time through LDS; lane 0
+            // adds them in order (serial by definition of this launcher).
+            double acc = 0;
+            for (uint64_t c = base; c < (uint64_t)end; c += STREAM_NNZ) {
+                const uint32_t cn = (uint32_t)((uint64_t)end - c < (uint64_t)STREAM_NNZ ? (uint64_t)end - c : (uint64_t)STREAM_NNZ);
+#pragma unroll
+                for (int u = 0; u < STREAM_UNROLL; ++u) {
+                    const uint32_t k = tid + u * WG_THREADS;
+                    if (k < cn) prod[k] = stream_load(AS + c + k) * x[stream_load(JA + c + k)];
+                }
+                __syncthreads();
+                if (tid == 0)
+                    for (uint32_t j = 0; j < cn; ++j) acc += prod[j];
+                __syncthreads();
+            }
+            if (tid == 0) y[r0] = acc;
+            return;
+        }
+        // wavefront semantics: workgroup-per-row, lane-strided partial sums
         double acc0 = 0, acc1 = 0, acc2 = 0, acc3 = 0;
-        I j = base + tid;
-        for (; j + 3 * WG_THREADS < end; j += 4 * WG_THREADS) {
+        uint64_t j = (uint64_t)base + tid;
+        const uint64_t e64 = end;
+        for (; j + 3 * WG_THREADS < e64; j += 4 * WG_THREADS) {
             const uint32_t c0 = stream_load(JA + j), c1 = stream_load(JA + j + WG_THREADS),
                            c2 = stream_load(JA + j + 2 * WG_THREADS), c3 = stream_load(JA + j + 3 * WG_THREADS);
             const double a0 = stream_load(AS + j), a1 = stream_load(AS + j + WG_THREADS),
                          a2 = stream_load(AS + j + 2 * WG_THREADS), a3 = stream_load(AS + j + 3 * WG_THREADS);
             acc0 += a0 * x[c0]; acc1 += a1 * x[c1]; acc2 += a2 * x[c2]; acc3 += a3 * x[c3];
         }
-        for (; j < end; j += WG_THREADS) acc0 += stream_load(AS + j) * x[stream_load(JA + j)];
+        for (; j < e64; j += WG_THREADS) acc0 += stream_load(AS + j) * x[stream_load(JA + j)];
         double acc = wave_sum((acc0 + acc1) + (acc2 + acc3));
         if (tid % WAVE == 0) wpart[tid / WAVE] = acc;
         __syncthreads();

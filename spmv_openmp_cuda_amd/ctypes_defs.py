@@ -1,5 +1,5 @@
 """ctypes mirrors of the C structs in include/spmv_types.h (spmat, CONFIG) and of
-the reference's own layout (for oracle/_ref/libspmvref.so only).
+the reference's own layout (for the compiled reference under oracle/_ref only).
 
 Reference definitions: src/include/sparseMatrix.h:25-42, src/include/config.h:21-32.
 """

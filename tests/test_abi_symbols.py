@@ -1,0 +1,70 @@
+"""The C-ABI libraries load and export every function their headers declare
+(no compute calls: runs without a GPU)."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+from conftest import ROOT
+
+INC = os.path.join(ROOT, "include")
+LIBDIR = os.path.join(ROOT, "spmv_openmp_cuda_amd", "lib")
+
+DECL = re.compile(r"^\s*(?:int|double|void|spmat\s*\*|double\s*\*|COMPUTE_MODE|MatrixMarket\s*\*|entry\s*\*|uint64_t)\s*\**\s*"
+                  r"([A-Za-z_][A-Za-z0-9_]*)\s*\(", re.M)
+SPMV_DECL = re.compile(r"^\s*SPMV(?:_HIP)?\s+([A-Za-z_][A-Za-z0-9_]*)\s*;", re.M)
+
+
+def declared(header, skip_blocks=()):
+    text = open(os.path.join(INC, header)).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    for start, end in skip_blocks:
+        text = re.sub(re.escape(start) + r".*?" + re.escape(end), "", text, flags=re.S)
+    names = set(DECL.findall(text)) | set(SPMV_DECL.findall(text))
+    return {n for n in names if not n.startswith("static") and n not in ("spmvModeIsGpu", "spmvModeIsCsr")}
+
+
+def test_gpu_library_exports_its_header():
+    lib = C.CDLL(os.path.join(LIBDIR, "libspmvhip.so"))
+    names = declared("spmvHip.h")
+    assert len(names) >= 40, names
+    missing = [n for n in sorted(names) if not hasattr(lib, n)]
+    assert not missing, f"declared in include/spmvHip.h but not exported: {missing}"
+    # the launchers listed in the dispatch tables of SpMV.h
+    for n in ("hipSpMVRowsCSR", "hipSpMVWarpPerRowCSR", "hipSpMVRowsELL", "hipSpMVRowsELLNNTransposed",
+              "hipSpMVWarpsPerRowELLNTrasposed"):
+        assert hasattr(lib, n)
+
+
+def test_host_library_exports_its_headers():
+    lib = C.CDLL(os.path.join(LIBDIR, "libspmvhost.so"))
+    names = declared("parser.h") | declared("utils.h") | declared("sparseMatrix.h")
+    names |= {"spmvModeFromString"}
+    missing = [n for n in sorted(names) if not hasattr(lib, n)]
+    assert not missing, f"declared in include/*.h but not exported by libspmvhost.so: {missing}"
+
+
+def test_oracle_exports_the_cpu_side_of_the_dispatch_surface():
+    lib = C.CDLL(os.path.join(ROOT, "oracle", "liboracle.so"))
+    for n in ("sgemvSerial", "spmvRowsBasicCSR", "spmvRowsBasicELL", "chunksNOOP", "chunksFair",
+              "chunksFairFolded", "ompGetRuntimeSchedule"):
+        assert hasattr(lib, n)
+
+
+def test_no_gpu_means_loud_failure_not_fallback(capfd):
+    """Without a device spmvHipInit must fail; nothing may silently compute on the CPU."""
+    lib = C.CDLL(os.path.join(LIBDIR, "libspmvhip.so"))
+    if lib.spmvHipDeviceCount() > 0:
+        pytest.skip("a GPU is visible here")
+    from spmv_openmp_cuda_amd import api
+    with pytest.raises(api.SpmvHipError):
+        api.spmvHipInit(0)
+    assert "no CPU fallback" in capfd.readouterr().err
+    # product sources never load, link or import the checker
+    banned = ("liboracle", "libspmvref", "-loracle", "import oracle", "from oracle")
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "spmv_openmp_cuda_amd")):
+        for f in files:
+            if f.endswith((".py", ".c", ".hip", ".hpp", ".h")):
+                src = open(os.path.join(dirpath, f), errors="ignore").read()
+                assert not [b for b in banned if b in src], f

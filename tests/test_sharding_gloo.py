@@ -1,0 +1,65 @@
+"""The N > 1 path on CPU: world_size-2 (and 3) gloo process groups run the same
+sharding code bench.py uses on RCCL (spmv_openmp_cuda_amd/sharding.py): nnz-balanced
+row blocks, padded in-place all-gather of y, compaction.  The per-rank SpMV is
+done by the oracle here (no GPU in this container); the gathered y must equal
+the serial oracle's y on the whole matrix BITWISE on every rank."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, equal_rows, out_dir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from conftest import Oracle
+    from spmv_openmp_cuda_amd import sharding, synth
+    oracle = Oracle()
+    if equal_rows:
+        w = synth.Workload("u", 6000, 6000 * 8, "uniform", cfg=8)
+    else:
+        w = synth.Workload("p", 5003, 90000, "powerlaw", 3000, 9)
+    lens = synth.row_lengths(w)
+    irp = synth.prefix(lens)
+    plan = sharding.make_plan(irp, world)
+    r0, r1 = plan.rows(rank)
+    # this rank's shard, generated independently with its row offset (as on the GPUs)
+    ja, as_ = oracle.synth_fill(w.N, r0, irp[r0:r1 + 1], synth.SEED_STRUCT + w.cfg, synth.SEED_VAL + w.cfg, 0)
+    x = synth.make_x(w.N, w.cfg)
+    irp_local = (irp[r0:r1 + 1] - irp[r0]).astype(np.uint32)
+    y_local = oracle.csr_serial_dev(irp_local, ja, as_, x)
+    ypad, slot, y = sharding.alloc_buffers(plan, rank, torch, "cpu")
+    slot[: r1 - r0].copy_(torch.from_numpy(y_local))
+    sharding.gather_y(plan, dist, ypad, slot, y)
+    # reference: the whole matrix on one "device"
+    ja_all, as_all = oracle.synth_fill(w.N, 0, irp, synth.SEED_STRUCT + w.cfg, synth.SEED_VAL + w.cfg, 0)
+    y_ref = oracle.csr_serial_dev(irp.astype(np.uint32), ja_all, as_all, x)
+    ok = np.array_equal(y.numpy(), y_ref) and not np.isnan(y.numpy()).any()
+    ok = ok and plan.equal_blocks == bool(equal_rows and w.N % world == 0)
+    with open(os.path.join(out_dir, f"rank{rank}.txt"), "w") as f:
+        f.write("ok" if ok else "mismatch")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,equal_rows", [(2, False), (2, True), (3, False)])
+def test_sharded_spmv_gloo(tmp_path, world, equal_rows):
+    port = _free_port()
+    mp.spawn(_worker, args=(world, port, equal_rows, str(tmp_path)), nprocs=world, join=True)
+    for r in range(world):
+        assert (tmp_path / f"rank{r}.txt").read_text() == "ok"
