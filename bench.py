@@ -122,7 +122,7 @@ def measure_single(api, synth, torch, w, launcher, steps, warmup):
     return res, dict(dm=dm, irp=irp, x_host=x_host, y=y, x=x, lens=lens)
 
 
-def cpu_baseline_and_check(api, synth, w, irp, x_host, y_gpu_head, sample_nnz, iters=5):
+def cpu_baseline_and_check(api, synth, w, irp, x_host, y_gpu_fn, sample_nnz, iters=5):
     """Time the reference's spmvRowsBasicCSR (oracle/_ref) -- or the oracle port --
     on the first rows of the workload (<= sample_nnz nnz) with all host cores, and
     use its y as the checker for the GPU's y on those rows."""
@@ -180,12 +180,32 @@ def cpu_baseline_and_check(api, synth, w, irp, x_host, y_gpu_head, sample_nnz, i
             ora.oracleCsrOmp32(rows, irp32.ctypes.data_as(vp), ja32.ctypes.data_as(vp), as_.ctypes.data_as(vp),
                                x_host.ctypes.data_as(vp), y_cpu.ctypes.data_as(vp))
             times.append(time.perf_counter() - t0)
+    # spot checks away from the head of the matrix (a wrapped grid or a wrong row-block table would show here)
+    spot = []
+    ora.oracleCsrSerial64_32.argtypes = [C.c_ulong, vp, vp, vp, vp, vp]
+    for r0 in (w.N // 2, max(0, w.N - 200_000)):
+        r1 = min(w.N, r0 + 200_000)
+        irp_r = np.ascontiguousarray(irp[r0:r1 + 1], dtype=np.uint64)
+        nz = int(irp_r[-1] - irp_r[0])
+        jr = np.empty(nz, dtype=np.uint32)
+        ar = np.empty(nz, dtype=np.float64)
+        ora.synthFillCsrRef(r1 - r0, w.N, r0, irp_r.ctypes.data_as(vp), jr.ctypes.data_as(vp), ar.ctypes.data_as(vp),
+                            synth.SEED_STRUCT + w.cfg, synth.SEED_VAL + w.cfg, w.band)
+        yr = np.empty(r1 - r0)
+        irp_l = irp_r - irp_r[0]
+        ora.oracleCsrSerial64_32(r1 - r0, irp_l.ctypes.data_as(vp), jr.ctypes.data_as(vp), ar.ctypes.data_as(vp),
+                                 x_host.ctypes.data_as(vp), yr.ctypes.data_as(vp))
+        yg = y_gpu_fn(r0, r1)
+        spot.append({"rows": [int(r0), int(r1)], "max_abs_diff": float(np.max(np.abs(yr - yg))),
+                     "nan": bool(np.isnan(yg).any())})
     times = times[1:]                                             # first pass = page-in
     t = sum(times) / len(times)
-    diff = np.abs(y_cpu - y_gpu_head[:rows])
+    y_gpu_head = y_gpu_fn(0, rows)
+    diff = np.abs(y_cpu - y_gpu_head)
     parity = {"rows_checked": rows, "max_abs_diff": float(np.nanmax(diff)), "gate_abs": 7e-4,
-              "nan_in_gpu_y": bool(np.isnan(y_gpu_head[:rows]).any()),
-              "ok": bool(not np.isnan(y_gpu_head[:rows]).any() and np.nanmax(diff) <= 7e-4)}
+              "nan_in_gpu_y": bool(np.isnan(y_gpu_head).any()), "spot_checks": spot,
+              "ok": bool(not np.isnan(y_gpu_head).any() and np.nanmax(diff) <= 7e-4 and
+                         all(not c["nan"] and c["max_abs_diff"] <= 7e-4 for c in spot))}
     base = {"value": 2.0 * nnz_s / t * 1e-9, "unit": "GFLOP/s", "cores": int(cores), "kind": kind,
             "sample": f"rows [0,{rows}) of the workload = {nnz_s} nnz, x full length, {len(times)} timed passes of "
                       f"spmvRowsBasicCSR, OMP schedule static, {t * 1e3:.2f} ms/pass",
@@ -227,10 +247,11 @@ def main():
             f"{res['hbm_gbps']:.0f} GB/s = {100 * res['hbm_frac']:.1f}% of 8 TB/s   (setup {time.perf_counter() - t_setup:.1f}s)")
         cpu_base, parity = None, None
         if not args.no_cpu_baseline:
-            head_rows = min(w.N, 8_000_000)
-            y_head = ctx["y"][:head_rows].cpu().numpy()
-            cpu_base, parity = cpu_baseline_and_check(api, synth, w, ctx["irp"], ctx["x_host"], y_head,
-                                                      args.cpu_sample_nnz)
+            y_t = ctx["y"]
+            cpu_base, parity = cpu_baseline_and_check(api, synth, w, ctx["irp"], ctx["x_host"],
+                                                      lambda a, b: y_t[a:b].cpu().numpy(), args.cpu_sample_nnz)
+            if not parity["ok"]:
+                raise SystemExit(f"PARITY FAILURE against the CPU checker: {parity}")
             log("cpu_baseline", cpu_base, "parity", parity)
         ctx["dm"].free()
         del ctx

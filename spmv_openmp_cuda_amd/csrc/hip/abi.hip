@@ -151,11 +151,11 @@ __global__ void fill64_kernel(uint64_t* p, size_t n, uint64_t v) {
 template <bool SEQ>
 static void launchStream(DevMat* d, double* x, double* y) {
     if (d->irpBytes == 4)
-        hipLaunchKernelGGL((csr_stream_kernel<uint32_t, SEQ>), dim3(d->nBlk), dim3(WG_THREADS), 0, S.stream,
-                           d->blkRow, static_cast<const uint32_t*>(d->IRP), d->JA, d->AS, x, y);
+        hipLaunchKernelGGL((csr_stream_kernel<uint32_t, SEQ>), grid2d(d->nBlk, WG_THREADS), dim3(WG_THREADS), 0, S.stream,
+                           d->nBlk, d->blkRow, static_cast<const uint32_t*>(d->IRP), d->JA, d->AS, x, y);
     else
-        hipLaunchKernelGGL((csr_stream_kernel<uint64_t, SEQ>), dim3(d->nBlk), dim3(WG_THREADS), 0, S.stream,
-                           d->blkRow, static_cast<const uint64_t*>(d->IRP), d->JA, d->AS, x, y);
+        hipLaunchKernelGGL((csr_stream_kernel<uint64_t, SEQ>), grid2d(d->nBlk, WG_THREADS), dim3(WG_THREADS), 0, S.stream,
+                           d->nBlk, d->blkRow, static_cast<const uint64_t*>(d->IRP), d->JA, d->AS, x, y);
 }
 
 
@@ -439,14 +439,14 @@ int hipSpMVRowsCSR(spmat* dMat, double* dX, CONFIG cfg, double* dY) {
     if (d->M == 0) return EXIT_SUCCESS;
     if (S.variantRowsCSR == 0) {
         const unsigned bt = blockThreads(cfg, BLOCKS_1D, 1024);
-        const dim3 grid((unsigned)((d->M + bt - 1) / bt)), block(bt);
+        const dim3 grid = grid2d((d->M + bt - 1) / bt, bt), block(bt);
         Launch L(grid, block);
         const uint32_t M = (uint32_t)d->M;
         if (d->irpBytes == 4) hipLaunchKernelGGL((csr_scalar_kernel<uint32_t>), grid, block, 0, S.stream, M, static_cast<const uint32_t*>(d->IRP), d->JA, d->AS, dX, dY);
         else                  hipLaunchKernelGGL((csr_scalar_kernel<uint64_t>), grid, block, 0, S.stream, M, static_cast<const uint64_t*>(d->IRP), d->JA, d->AS, dX, dY);
         return L.finish("hipSpMVRowsCSR");
     }
-    Launch L(dim3(d->nBlk), dim3(WG_THREADS));
+    Launch L(grid2d(d->nBlk, WG_THREADS), dim3(WG_THREADS));
     launchStream<true>(d, dX, dY);
     return L.finish("hipSpMVRowsCSR");
 }
@@ -459,14 +459,14 @@ int hipSpMVWarpPerRowCSR(spmat* dMat, double* dX, CONFIG cfg, double* dY) {
     if (S.variantWarpCSR == 0) {
         const unsigned bt = blockThreads(cfg, WAVESIZE * BLOCKS_2D_WARP_R, 1024);
         const unsigned rowsPerWg = bt / WAVE;
-        const dim3 grid((unsigned)((d->M + rowsPerWg - 1) / rowsPerWg)), block(bt);
+        const dim3 grid = grid2d((d->M + rowsPerWg - 1) / rowsPerWg, bt), block(bt);
         Launch L(grid, block);
         const uint32_t M = (uint32_t)d->M;
         if (d->irpBytes == 4) hipLaunchKernelGGL((csr_vector_kernel<uint32_t>), grid, block, 0, S.stream, M, static_cast<const uint32_t*>(d->IRP), d->JA, d->AS, dX, dY);
         else                  hipLaunchKernelGGL((csr_vector_kernel<uint64_t>), grid, block, 0, S.stream, M, static_cast<const uint64_t*>(d->IRP), d->JA, d->AS, dX, dY);
         return L.finish("hipSpMVWarpPerRowCSR");
     }
-    Launch L(dim3(d->nBlk), dim3(WG_THREADS));
+    Launch L(grid2d(d->nBlk, WG_THREADS), dim3(WG_THREADS));
     launchStream<false>(d, dX, dY);
     return L.finish("hipSpMVWarpPerRowCSR");
 }
@@ -477,7 +477,7 @@ int hipSpMVRowsELL(spmat* dMat, double* dX, CONFIG cfg, double* dY) {
     if (d->kind != Kind::ELL_COLMAJOR) { ERR("hipSpMVRowsELL: expects the transposed (column-major) ELL upload: ellTranspose() + spMatCpyELL()"); return EXIT_FAILURE; }
     if (d->M == 0) return EXIT_SUCCESS;
     const unsigned bt = blockThreads(cfg, BLOCKS_1D, 1024);
-    const dim3 grid((unsigned)((d->M + bt - 1) / bt)), block(bt);
+    const dim3 grid = grid2d((d->M + bt - 1) / bt, bt), block(bt);
     Launch L(grid, block);
     const bool rl = S.ellRowLens && d->RL;
     if (rl) hipLaunchKernelGGL((ell_colmajor_thread<true>), grid, block, 0, S.stream, (uint32_t)d->M, (uint32_t)d->K, d->pitch, d->JA, d->AS, d->RL, dX, dY);
@@ -491,7 +491,7 @@ int hipSpMVRowsELLNNTransposed(spmat* dMat, double* dX, CONFIG cfg, double* dY) 
     if (d->kind != Kind::ELL_ROWMAJOR) { ERR("hipSpMVRowsELLNNTransposed: expects the row-major ELL upload (no ellTranspose)"); return EXIT_FAILURE; }
     if (d->M == 0) return EXIT_SUCCESS;
     const unsigned bt = blockThreads(cfg, BLOCKS_1D, 1024);
-    const dim3 grid((unsigned)((d->M + bt - 1) / bt)), block(bt);
+    const dim3 grid = grid2d((d->M + bt - 1) / bt, bt), block(bt);
     Launch L(grid, block);
     const bool rl = S.ellRowLens && d->RL;
     if (rl) hipLaunchKernelGGL((ell_rowmajor_thread<true>), grid, block, 0, S.stream, (uint32_t)d->M, (uint32_t)d->K, d->pitch, d->JA, d->AS, d->RL, dX, dY);
@@ -510,7 +510,7 @@ int hipSpMVWarpsPerRowELLNTrasposed(spmat* dMat, double* dX, CONFIG cfg, double*
     const unsigned bt = WG_THREADS;
     (void)cfg;
     const uint64_t threads = d->M * (uint64_t)G;
-    const dim3 grid((unsigned)((threads + bt - 1) / bt)), block(bt);
+    const dim3 grid = grid2d((threads + bt - 1) / bt, bt), block(bt);
     Launch L(grid, block);
     const bool rl = S.ellRowLens && d->RL;
     switch (G) {

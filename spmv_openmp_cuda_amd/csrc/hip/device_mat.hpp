@@ -44,6 +44,16 @@ struct DevMat {
     uint64_t  maxRowNnz = 0;
 };
 
+// Fold `blocks` workgroups into an (x, y) grid whose x extent keeps
+// x * threads < 2^32 (AQL grid_size is 32-bit work-items per dimension).
+// Kernels use linear_block() and bounds-check against the real block count.
+inline dim3 grid2d(uint64_t blocks, unsigned threads) {
+    const uint64_t maxX = ((1ull << 32) - 1) / threads;         // >= 4 M blocks for <= 1024 threads
+    if (blocks <= maxX) return dim3((unsigned)(blocks ? blocks : 1), 1, 1);
+    const uint64_t gx = 1ull << 20;
+    return dim3((unsigned)gx, (unsigned)((blocks + gx - 1) / gx), 1);
+}
+
 inline bool hipOk(hipError_t e, const char* what) {
     if (e == hipSuccess) return true;
     fprintf(stderr, "\33[31m\33[1m\33[44mlibspmvhip: %s\t%s\33[0m\n", what, hipGetErrorString(e));

@@ -21,6 +21,12 @@
 
 namespace spmvhip {
 
+// The AQL dispatch packet stores the grid size in WORK-ITEMS as 32 bits per
+// dimension: blocks * threads must stay below 2^32 or the launch silently wraps.
+// Launchers therefore fold large grids into (x, y) -- see grid2d() in
+// device_mat.hpp -- and kernels recover the linear workgroup id here.
+__device__ __forceinline__ uint64_t linear_block() { return (uint64_t)blockIdx.y * gridDim.x + blockIdx.x; }
+
 // streamed-once data: keep it out of the way of x in L2 / Infinity Cache
 template <typename T>
 __device__ __forceinline__ T stream_load(const T* p) { return __builtin_nontemporal_load(p); }
@@ -52,8 +58,9 @@ template <typename I>
 __global__ __launch_bounds__(WG_THREADS) void csr_scalar_kernel(
     uint32_t M, const I* __restrict__ IRP, const uint32_t* __restrict__ JA,
     const double* __restrict__ AS, const double* __restrict__ x, double* __restrict__ y) {
-    const uint32_t row = blockIdx.x * blockDim.x + threadIdx.x;
-    if (row >= M) return;
+    const uint64_t gid = linear_block() * blockDim.x + threadIdx.x;
+    if (gid >= M) return;
+    const uint32_t row = (uint32_t)gid;
     const I b = IRP[row], e = IRP[row + 1];
     double acc = 0;
     for (I j = b; j < e; ++j) acc += AS[j] * x[JA[j]];
@@ -67,9 +74,10 @@ __global__ __launch_bounds__(1024) void csr_vector_kernel(
     uint32_t M, const I* __restrict__ IRP, const uint32_t* __restrict__ JA,
     const double* __restrict__ AS, const double* __restrict__ x, double* __restrict__ y) {
     const uint32_t wavesPerWg = blockDim.x / WAVE;
-    const uint32_t row  = blockIdx.x * wavesPerWg + threadIdx.x / WAVE;   // wave-uniform
+    const uint64_t grow = linear_block() * wavesPerWg + threadIdx.x / WAVE;   // wave-uniform
     const uint32_t lane = threadIdx.x % WAVE;
-    if (row >= M) return;
+    if (grow >= M) return;
+    const uint32_t row = (uint32_t)grow;
     const I b = IRP[row], e = IRP[row + 1];
     double acc = 0;
     for (I j = b + lane; j < e; j += WAVE) acc += stream_load(AS + j) * x[stream_load(JA + j)];
@@ -91,14 +99,16 @@ constexpr int STREAM_UNROLL = STREAM_NNZ / WG_THREADS;
 
 template <typename I, bool SEQ>
 __global__ __launch_bounds__(WG_THREADS) void csr_stream_kernel(
-    const uint32_t* __restrict__ blkRow, const I* __restrict__ IRP,
+    uint32_t nBlk, const uint32_t* __restrict__ blkRow, const I* __restrict__ IRP,
     const uint32_t* __restrict__ JA, const double* __restrict__ AS,
     const double* __restrict__ x, double* __restrict__ y) {
     __shared__ double prod[STREAM_NNZ];
     __shared__ double wpart[WG_THREADS / WAVE];
 
     const uint32_t tid = threadIdx.x;
-    const uint32_t r0 = blkRow[blockIdx.x], r1 = blkRow[blockIdx.x + 1];
+    const uint64_t blk = linear_block();
+    if (blk >= nBlk) return;                    // whole workgroup leaves together
+    const uint32_t r0 = blkRow[blk], r1 = blkRow[blk + 1];
     const I base = IRP[r0], end = IRP[r1];
 
     if (end - base > (I)STREAM_NNZ) {
@@ -211,8 +221,9 @@ __global__ __launch_bounds__(WG_THREADS) void ell_colmajor_thread(
     uint32_t rows, uint32_t slots, size_t pitch, const uint32_t* __restrict__ JA,
     const double* __restrict__ AS, const uint32_t* __restrict__ RL,
     const double* __restrict__ x, double* __restrict__ y) {
-    const uint32_t row = blockIdx.x * blockDim.x + threadIdx.x;
-    if (row >= rows) return;
+    const uint64_t gid = linear_block() * blockDim.x + threadIdx.x;
+    if (gid >= rows) return;
+    const uint32_t row = (uint32_t)gid;
     const uint32_t n = USE_RL ? RL[row] : slots;
     double acc = 0;
     size_t idx = row;
@@ -236,8 +247,9 @@ __global__ __launch_bounds__(WG_THREADS) void ell_rowmajor_thread(
     uint32_t rows, uint32_t slots, size_t pitch, const uint32_t* __restrict__ JA,
     const double* __restrict__ AS, const uint32_t* __restrict__ RL,
     const double* __restrict__ x, double* __restrict__ y) {
-    const uint32_t row = blockIdx.x * blockDim.x + threadIdx.x;
-    if (row >= rows) return;
+    const uint64_t gid = linear_block() * blockDim.x + threadIdx.x;
+    if (gid >= rows) return;
+    const uint32_t row = (uint32_t)gid;
     const uint32_t n = USE_RL ? RL[row] : slots;
     const size_t p = (size_t)row * pitch;
     double acc = 0;
@@ -253,7 +265,7 @@ __global__ __launch_bounds__(WG_THREADS) void ell_rowmajor_group(
     uint32_t rows, uint32_t slots, size_t pitch, const uint32_t* __restrict__ JA,
     const double* __restrict__ AS, const uint32_t* __restrict__ RL,
     const double* __restrict__ x, double* __restrict__ y) {
-    const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t gid = linear_block() * blockDim.x + threadIdx.x;
     const uint64_t row = gid / G;
     const uint32_t l = (uint32_t)(gid % G);
     const bool live = row < rows;

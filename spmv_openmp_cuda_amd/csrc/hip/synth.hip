@@ -28,7 +28,7 @@ template <typename I>
 __global__ __launch_bounds__(256) void synth_fill_kernel(
     uint64_t M, uint64_t N, uint64_t rowOffset, const I* __restrict__ IRP, uint32_t* __restrict__ JA,
     double* __restrict__ AS, uint64_t seedStruct, uint64_t seedVal, uint64_t band) {
-    const uint64_t i = (uint64_t)blockIdx.x * (blockDim.x / 64) + threadIdx.x / 64;
+    const uint64_t i = ((uint64_t)blockIdx.y * gridDim.x + blockIdx.x) * (blockDim.x / 64) + threadIdx.x / 64;
     if (i >= M) return;
     const uint32_t lane = threadIdx.x % 64;
     const uint64_t base0 = IRP[0];
@@ -63,12 +63,12 @@ extern "C" int spmvHipSynthFillCSR(ulong M, ulong N, ulong rowOffset, const void
         return EXIT_FAILURE;
     }
     const uint64_t blocks = (M + 3) / 4;
-    if (blocks > 0x7FFFFFFFull) { fprintf(stderr, "libspmvhip: spmvHipSynthFillCSR: too many rows\n"); return EXIT_FAILURE; }
+    const dim3 grid = spmvhip::grid2d(blocks, 256);     // 2-D when blocks*256 would overflow the 32-bit work-item count
     if (irpBytes == 4)
-        hipLaunchKernelGGL((synth_fill_kernel<uint32_t>), dim3((unsigned)blocks), dim3(256), 0, nullptr, M, N, rowOffset,
+        hipLaunchKernelGGL((synth_fill_kernel<uint32_t>), grid, dim3(256), 0, nullptr, M, N, rowOffset,
                            static_cast<const uint32_t*>(dIRP), dJA, dAS, seedStruct, seedVal, band);
     else
-        hipLaunchKernelGGL((synth_fill_kernel<uint64_t>), dim3((unsigned)blocks), dim3(256), 0, nullptr, M, N, rowOffset,
+        hipLaunchKernelGGL((synth_fill_kernel<uint64_t>), grid, dim3(256), 0, nullptr, M, N, rowOffset,
                            static_cast<const uint64_t*>(dIRP), dJA, dAS, seedStruct, seedVal, band);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipDeviceSynchronize());

@@ -161,3 +161,48 @@ def test_synth_device_matches_twin_and_oracle(api, oracle):
             assert np.array_equal(sh.buffers["AS"].down(np.float64), as_ref[b0:b1])
             sh.free()
             dm.free()
+
+
+@pytest.mark.parametrize("key", ["c3", "c5"])
+def test_full_size_spot_checks(api, oracle, key):
+    """BASELINE.json's full sizes (10 M / 200 M and 80 M / 1.6 G): the whole y must be
+    written (no poison left) and rows at the start, middle, end and around the
+    heaviest row must match the oracle.  (A launch whose blocks*threads wrapped the
+    32-bit work-item count once left most of c5 unfilled -- this is its regression test.)"""
+    from spmv_openmp_cuda_amd import synth
+    w = synth.WORKLOADS[key]
+    lens = synth.row_lengths(w)
+    irp = synth.prefix(lens)
+    dm = synth.device_csr(w, irp, 0, w.N)
+    x = synth.make_x(w.N, w.cfg)
+    dx = api.DeviceVector(w.N).up(x)
+    dy = api.DeviceVector(w.N)
+    S = 100_000
+    heavy = int(np.argmax(lens))
+    ranges = [(0, S), (w.N // 2, w.N // 2 + S), (w.N - S, w.N), (max(0, heavy - 10), min(w.N, heavy + 10))]
+    refs = []
+    for r0, r1 in ranges:
+        ja, as_ = oracle.synth_fill(w.N, r0, irp[r0:r1 + 1], synth.SEED_STRUCT + w.cfg, synth.SEED_VAL + w.cfg, w.band)
+        # the device generator wrote the same entries
+        b0, b1 = int(irp[r0]), int(irp[r1])
+        ja_dev = np.empty(b1 - b0, dtype=np.uint32)
+        api.lib.spmvHipMemcpyDown(ja_dev.ctypes.data_as(__import__("ctypes").c_void_p),
+                                  dm.buffers["JA"].ptr.value + 4 * b0, 4 * (b1 - b0))
+        assert np.array_equal(ja_dev, ja)
+        refs.append(oracle.csr_serial_dev((irp[r0:r1 + 1] - irp[r0]).astype(np.uint32), ja, as_, x))
+    for launcher, exact in (("hipSpMVWarpPerRowCSR", False), ("hipSpMVRowsCSR", True)):
+        dy.poison()
+        api.spmv(launcher, dm, dx, dy)
+        y = dy.down()
+        assert not np.isnan(y).any(), "poison survived: some rows were never written"
+        for (r0, r1), yr in zip(ranges, refs):
+            assert np.max(np.abs(y[r0:r1] - yr)) <= GATE
+            if exact:
+                assert np.array_equal(y[r0:r1], yr)
+        # linearity (size-independent property): A(2x) == 2 A(x) exactly in binary fp
+        dx2 = api.DeviceVector(w.N).up(2.0 * x)
+        dy.poison()
+        api.spmv(launcher, dm, dx2, dy)
+        assert np.array_equal(dy.down(), 2.0 * y)
+        dx2.free()
+    dm.free()
