@@ -44,7 +44,9 @@ def parse():
     p.add_argument("--warmup", type=int, default=3)
     p.add_argument("--workload", default="c5")
     p.add_argument("--scale", type=float, default=1.0, help="shrink/grow the workload (rows and nnz) by this factor")
-    p.add_argument("--launcher", default="hipSpMVWarpPerRowCSR")
+    p.add_argument("--launcher", default="auto",
+                   help="a C-ABI launcher name, or 'auto': time hipSpMVWarpPerRowCSR (one-pass LDS-stream kernel) and "
+                        "hipSpMVTilesCSR (column-sliced two-phase kernel) during warm-up and keep the faster")
     p.add_argument("--variant", type=int, default=-1)
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-extra", action="store_true", help="skip the secondary workloads measured at N=1")
@@ -78,6 +80,40 @@ def kernel_ms(api, ev_pairs):
     return out
 
 
+AUTO_CANDIDATES = ("hipSpMVWarpPerRowCSR", "hipSpMVTilesCSR")
+
+
+def pick_launcher(api, torch, dm, x_ptr, y_ptr, requested):
+    """'auto' -> run each candidate 3x (first call of the tiles launcher also builds its
+    slice-major format) and keep the faster; returns (name, {name: ms})."""
+    if requested != "auto":
+        return requested, {}
+    cfg = api.CONFIG()
+    times = {}
+    for name in AUTO_CANDIDATES:
+        fn = api.SPMV_LAUNCHERS[name]
+        if fn(C.byref(dm.handle), x_ptr, cfg, y_ptr):
+            continue                                  # e.g. tiles unsupported for this shape: skip
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            fn(C.byref(dm.handle), x_ptr, cfg, y_ptr)
+        torch.cuda.synchronize()
+        times[name] = (time.perf_counter() - t0) / 3 * 1e3
+    best = min(times, key=times.get)
+    return best, times
+
+
+def pmc_traffic(workload_name, launcher):
+    """HBM bytes per launch measured by separate rocprofv3 --pmc passes of this command
+    (profiles/traffic.json, written by scripts/summarize_profile.py runs); None if not profiled."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
+            return json.load(f).get(workload_name, {}).get(launcher)
+    except OSError:
+        return None
+
+
 def measure_single(api, synth, torch, w, launcher, steps, warmup):
     """1-GPU measurement of workload `w`; returns (dict, context for checks)."""
     import numpy as np
@@ -88,6 +124,8 @@ def measure_single(api, synth, torch, w, launcher, steps, warmup):
     x_host = synth.make_x(w.N, w.cfg)
     x = torch.from_numpy(x_host).cuda()
     y = torch.full((w.N,), float("nan"), dtype=torch.float64, device="cuda")
+    launcher, tried = pick_launcher(api, torch, dm, x.data_ptr(), y.data_ptr(), launcher)
+    y.fill_(float("nan"))
     fn = api.SPMV_LAUNCHERS[launcher]
     cfg = api.CONFIG()
     evs = [(C.c_void_p(), C.c_void_p()) for _ in range(steps)]
@@ -113,7 +151,8 @@ def measure_single(api, synth, torch, w, launcher, steps, warmup):
     bytes_alg = synth.algorithmic_bytes_csr(nnz, w.N, w.N)
     k_avg = sum(kms) / len(kms) * 1e-3
     res = {
-        "workload": info, "launcher": launcher,
+        "workload": info, "launcher": launcher, "auto_candidates_ms": tried,
+        "extra_device_bytes": int(api.lib.spmvHipTilesBytes(C.byref(dm.handle))) if launcher == "hipSpMVTilesCSR" else 0,
         "ms_per_step": wall / steps * 1e3, "kernel_ms_avg": k_avg * 1e3, "kernel_ms_min": min(kms),
         "gflops": 2.0 * nnz / (wall / steps) * 1e-9,
         "hbm_gbps": bytes_alg / k_avg * 1e-9, "hbm_frac": bytes_alg / k_avg / HBM_PEAK,
@@ -231,7 +270,7 @@ def main():
     api.spmvHipInit(local)
     api.lib.spmvHipSetStream(C.c_void_p(torch.cuda.current_stream().cuda_stream))
     api.lib.spmvHipSetSync(0)
-    if args.variant >= 0:
+    if args.variant >= 0 and args.launcher != "auto":
         api.set_variant(args.launcher, args.variant)
 
     w = synth.WORKLOADS[args.workload]
@@ -243,7 +282,7 @@ def main():
     extra = {}
     if world == 1:
         res, ctx = measure_single(api, synth, torch, w, args.launcher, steps, warmup)
-        log(f"{w.name}: {res['gflops']:.1f} GFLOP/s  kernel {res['kernel_ms_avg']:.3f} ms  "
+        log(f"{w.name} [{res['launcher']}]: {res['gflops']:.1f} GFLOP/s  kernel {res['kernel_ms_avg']:.3f} ms  "
             f"{res['hbm_gbps']:.0f} GB/s = {100 * res['hbm_frac']:.1f}% of 8 TB/s   (setup {time.perf_counter() - t_setup:.1f}s)")
         cpu_base, parity = None, None
         if not args.no_cpu_baseline:
@@ -265,6 +304,7 @@ def main():
                     we = synth.scaled(we, args.scale)
                 launcher = "hipSpMVRowsCSR" if key.startswith("c2") else args.launcher
                 r, c = measure_single(api, synth, torch, we, launcher, steps, warmup)
+                launcher = r["launcher"]
                 c["dm"].free()
                 del c
                 torch.cuda.empty_cache()
@@ -276,10 +316,12 @@ def main():
             "warmup": warmup, "ms_per_step": res["ms_per_step"], "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": res["workload"]["workload"], **{k: v for k, v in res["workload"].items() if k != "workload"},
-                       "kernel": args.launcher, "parallelism": "1 GPU"},
+                       "kernel": res["launcher"], "auto_candidates_ms": res["auto_candidates_ms"],
+                       "parallelism": "1 GPU"},
             "hbm_gbps": res["hbm_gbps"], "hbm_roofline_frac": res["hbm_frac"],
             "roofline": {"bound": "hbm", "achieved": res["hbm_gbps"], "peak": HBM_PEAK * 1e-9, "unit": "GB/s",
-                         "frac": res["hbm_frac"], "traffic": None, "kernel": "csr_stream_kernel",
+                         "frac": res["hbm_frac"], "traffic": pmc_traffic(res["workload"]["workload"], res["launcher"]),
+                         "kernel": "pb_expand_kernel + pb_reduce_kernel" if res["launcher"] == "hipSpMVTilesCSR" else "csr_stream_kernel",
                          "algorithmic_bytes_per_launch": res["algorithmic_bytes"],
                          "kernel_ms_avg": res["kernel_ms_avg"]},
         }
@@ -296,26 +338,27 @@ def main():
         return
 
     # ------------------------------------------------------------------ N > 1
+    from spmv_openmp_cuda_amd import sharding
     lens = synth.row_lengths(w)
     irp = synth.prefix(lens)
     info = synth.describe(w, lens)
     del lens
-    bounds = api.partition_rows(irp, world).astype(np.int64)
-    rows_per = np.diff(bounds)
-    max_rows = int(rows_per.max())
-    r0, r1 = int(bounds[rank]), int(bounds[rank + 1])
+    plan = sharding.make_plan(irp, world)
+    r0, r1 = plan.rows(rank)
     dm = synth.device_csr(w, irp, r0, r1)
     nnz_total = int(irp[-1])
     nnz_local = int(irp[r1] - irp[r0])
     x_host = synth.make_x(w.N, w.cfg)
     x = torch.from_numpy(x_host).cuda()
     del x_host
-    ypad = torch.full((world * max_rows,), float("nan"), dtype=torch.float64, device="cuda")
-    y = torch.full((w.N,), float("nan"), dtype=torch.float64, device="cuda")
-    slot = ypad[rank * max_rows:(rank + 1) * max_rows]
-    bounds_u = np.ascontiguousarray(bounds, dtype=np.uint64)
-    equal_blocks = bool((rows_per == max_rows).all())
-    fn = api.SPMV_LAUNCHERS[args.launcher]
+    ypad, slot, y = sharding.alloc_buffers(plan, rank, torch, "cuda")
+    # every rank must run the same kernel: rank 0 decides
+    launcher, tried = pick_launcher(api, torch, dm, x.data_ptr(), slot.data_ptr(), args.launcher)
+    choice = torch.tensor([AUTO_CANDIDATES.index(launcher) if launcher in AUTO_CANDIDATES else -1], device="cuda")
+    dist.broadcast(choice, 0)
+    if int(choice) >= 0:
+        launcher = AUTO_CANDIDATES[int(choice)]
+    fn = api.SPMV_LAUNCHERS[launcher]
     cfg = api.CONFIG()
     evs = [(C.c_void_p(), C.c_void_p()) for _ in range(steps)]
     for a, b in evs:
@@ -329,9 +372,8 @@ def main():
         if ev:
             api.lib.spmvHipEventRecord(ev[1])
         if rc:
-            raise RuntimeError(args.launcher + " failed")
-        dist.all_gather_into_tensor(ypad, slot)                 # RCCL over xGMI, in place
-        api.lib.spmvHipCompactRows(y.data_ptr(), ypad.data_ptr(), bounds_u.ctypes.data_as(C.c_void_p), world, max_rows)
+            raise RuntimeError(launcher + " failed")
+        sharding.gather_y(plan, dist, ypad, slot, y)            # RCCL all-gather over xGMI, in place (+ compaction)
 
     wall = time_kernel_loop(api, torch, dist, world, step, steps, warmup, evs)
     kms = kernel_ms(api, evs)
@@ -352,14 +394,15 @@ def main():
             "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": wall_max / steps * 1e3,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": info["workload"], **{k: v for k, v in info.items() if k != "workload"},
-                       "kernel": args.launcher,
+                       "kernel": launcher, "auto_candidates_ms": tried,
                        "parallelism": f"{world} nnz-balanced row blocks + RCCL all-gather(y)" +
-                                      ("" if equal_blocks else " (padded blocks + compaction)")},
+                                      ("" if plan.equal_blocks else " (padded blocks + compaction)")},
             "hbm_gbps": bytes_alg_total / (wall_max / steps) * 1e-9,
             "hbm_roofline_frac": bytes_alg_total / (wall_max / steps) / (HBM_PEAK * world),
             "roofline": {"bound": "hbm", "achieved": bytes_alg_local / k_avg * 1e-9, "peak": HBM_PEAK * 1e-9,
                          "unit": "GB/s", "frac": bytes_alg_local / k_avg / HBM_PEAK, "traffic": None,
-                         "kernel": "csr_stream_kernel", "algorithmic_bytes_per_launch": bytes_alg_local,
+                         "kernel": "pb_expand_kernel + pb_reduce_kernel" if launcher == "hipSpMVTilesCSR" else "csr_stream_kernel",
+                         "algorithmic_bytes_per_launch": bytes_alg_local,
                          "kernel_ms_avg": kernel_ms_max, "note": "per-rank kernel, slowest rank"},
             "gather_ms_per_step": wall_max / steps * 1e3 - kernel_ms_max,
             "parity": {"all_ranks_hold_identical_y": bool(same), "nan_left": float(chk_all[0][2])},

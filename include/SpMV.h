@@ -33,6 +33,8 @@ extern "C" {
 #define CUDA_ELL_ROWS_NT        "CUDA_ELL_ROWS_NN_TRANSPOSED"      /* in the reference's table but not selectable from its CLI */
 #define CUDA_ELL_ROWS_WARP      "CUDA_ELL_ROWS_WARP"
 #define CUDA_ELL_ROWS_WARP_NT   "CUDA_ELL_ROWS_WARP_NN_TRANSPOSED"
+#define CUDA_CSR_TILES          "CUDA_CSR_TILES"                   /* new: column-sliced two-phase kernel */
+#define HIP_CSR_TILES           "HIP_CSR_TILES"
 #define HIP_CSR_ROWS            "HIP_CSR_ROWS"
 #define HIP_CSR_ROWS_WARP       "HIP_CSR_ROWS_WARP"
 #define HIP_ELL_ROWS            "HIP_ELL_ROWS"
@@ -54,6 +56,7 @@ typedef enum {              /* same order and values as SpMV.h:42-59 */
     _CUDA_ELL_ROWS_WARP,
     _CUDA_ELL_ROWS_WARP_NT,
     _CUDA_ELL_ROWS_NT,      /* appended: row-major thread-per-row ELL */
+    _CUDA_CSR_TILES,        /* appended: column-sliced two-phase CSR */
     _COMPUTE_MODE_INVALID = -1
 } COMPUTE_MODE;
 
@@ -61,7 +64,7 @@ typedef enum {              /* same order and values as SpMV.h:42-59 */
 COMPUTE_MODE spmvModeFromString(const char* name);
 static inline int spmvModeIsGpu(COMPUTE_MODE m) { return m >= _CUDA_CSR_ROWS; }
 static inline int spmvModeIsCsr(COMPUTE_MODE m) {
-    return m <= _CSR_TILES_ALLOCD || m == _CUDA_CSR_ROWS || m == _CUDA_CSR_ROWS_WARP;
+    return m <= _CSR_TILES_ALLOCD || m == _CUDA_CSR_ROWS || m == _CUDA_CSR_ROWS_WARP || m == _CUDA_CSR_TILES;
 }
 
 /* y = A x: (matrix, x, run configuration, y) -> EXIT_SUCCESS / EXIT_FAILURE */
@@ -72,8 +75,10 @@ typedef int (*SPMV_INTERF)(spmat*, double*, CONFIG*, double*);
 static const SPMV_HIP_INTERF SpmvCUDA_CSRFuncs[] = {
     &hipSpMVRowsCSR,
     &hipSpMVWarpPerRowCSR,
+    &hipSpMVTilesCSR,           /* appended: no counterpart in the reference's GPU table */
 };
 #define SpmvCUDA_CSRFuncs_WarpPerRowIdx     1
+#define SpmvCUDA_CSRFuncs_TilesIdx          2
 static const SPMV_HIP_INTERF SpmvCUDA_ELLFuncs[] = {
     &hipSpMVRowsELL,
     &hipSpMVRowsELLNNTransposed,

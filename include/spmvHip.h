@@ -99,6 +99,17 @@ SPMV_HIP hipSpMVRowsELL;                  /* <- cudaSpMVRowsELL (transposed)    
 SPMV_HIP hipSpMVRowsELLNNTransposed;      /* <- cudaSpMVRowsELLNNTransposed      SpMV_CUDA.cu:99-115  */
 SPMV_HIP hipSpMVWarpsPerRowELLNTrasposed; /* <- cudaSpMVWarpsPerRowELLNTrasposed SpMV_CUDA.cu:116-135 */
 
+/* Column-sliced two-phase SpMV for matrices whose x gather misses the caches
+ * (DESIGN.md section 7): the GPU counterpart of the reference's 2-D decomposed
+ * CPU variants spmvTilesCSR / spmvTilesAllocdCSR (src/SpMV_CSR_OMP.c:101-226:
+ * column partitions, partial results, final reduction).  The slice-major copy
+ * of the matrix (+20 B/nnz of device memory) is built on the device at the
+ * first call, or explicitly with spmvHipBuildTiles.  Row sums are added in
+ * arrival order (LDS atomics): equal to the oracle to rounding, not bitwise. */
+SPMV_HIP hipSpMVTilesCSR;
+int    spmvHipBuildTiles(spmat* dMat);
+size_t spmvHipTilesBytes(spmat* dMat);
+
 /* Enqueue-only form of the two CSR launchers on an explicit stream (no timing
  * bracket, no synchronisation): warpPerRow = 0 -> hipSpMVRowsCSR semantics,
  * != 0 -> hipSpMVWarpPerRowCSR.  The current device must be the matrix'. */

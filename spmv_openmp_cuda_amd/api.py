@@ -52,6 +52,9 @@ _sigs = {
     "hipFreeSpmat": ([C.POINTER(spmat)], _i),
     "spmvHipAdoptCSR": ([C.POINTER(spmat), C.c_ulong, C.c_ulong, C.c_ulong, _vp, _i, _vp, _vp, _vp], _i),
     "hipSpMVRowsCSR": (_SPMV_ARGS, _i), "hipSpMVWarpPerRowCSR": (_SPMV_ARGS, _i),
+    "hipSpMVTilesCSR": (_SPMV_ARGS, _i), "spmvHipBuildTiles": ([C.POINTER(spmat)], _i),
+    "spmvHipTilesBytes": ([C.POINTER(spmat)], _sz),
+    "spmvHipEnqueueCSR": ([C.POINTER(spmat), _i, _vp, _vp, _vp], _i),
     "hipSpMVRowsELL": (_SPMV_ARGS, _i), "hipSpMVRowsELLNNTransposed": (_SPMV_ARGS, _i),
     "hipSpMVWarpsPerRowELLNTrasposed": (_SPMV_ARGS, _i),
     "spmvHipSetVariant": ([C.c_char_p, _i], _i), "spmvHipSetEllRowLens": ([_i], _i),
@@ -94,6 +97,7 @@ for _name, (_args, _res) in _hsigs.items():
 SPMV_LAUNCHERS = {
     "hipSpMVRowsCSR": lib.hipSpMVRowsCSR,
     "hipSpMVWarpPerRowCSR": lib.hipSpMVWarpPerRowCSR,
+    "hipSpMVTilesCSR": lib.hipSpMVTilesCSR,
     "hipSpMVRowsELL": lib.hipSpMVRowsELL,
     "hipSpMVRowsELLNNTransposed": lib.hipSpMVRowsELLNNTransposed,
     "hipSpMVWarpsPerRowELLNTrasposed": lib.hipSpMVWarpsPerRowELLNTrasposed,

@@ -82,6 +82,7 @@ void freeDesc(DevMat* d) {
         (void)hipFree(d->IRP); (void)hipFree(d->JA); (void)hipFree(d->AS); (void)hipFree(d->RL);
     }
     (void)hipFree(d->blkRow);
+    freeTiles(d->tiles);
     d->magic = 0;
     delete d;
 }
@@ -469,6 +470,34 @@ int hipSpMVWarpPerRowCSR(spmat* dMat, double* dX, CONFIG cfg, double* dY) {
     Launch L(grid2d(d->nBlk, WG_THREADS), dim3(WG_THREADS));
     launchStream<false>(d, dX, dY);
     return L.finish("hipSpMVWarpPerRowCSR");
+}
+
+int spmvHipBuildTiles(spmat* dMat) {
+    DevMat* d = descOf(dMat, "spmvHipBuildTiles");
+    if (!d) return EXIT_FAILURE;
+    if (d->kind != Kind::CSR) { ERR("spmvHipBuildTiles: handle is not CSR"); return EXIT_FAILURE; }
+    return buildTiles(d);
+}
+size_t spmvHipTilesBytes(spmat* dMat) {
+    DevMat* d = descOf(dMat, "spmvHipTilesBytes");
+    return d ? tilesBytes(d) : 0;
+}
+
+int hipSpMVTilesCSR(spmat* dMat, double* dX, CONFIG cfg, double* dY) {
+    (void)cfg;
+    DevMat* d = descOf(dMat, "hipSpMVTilesCSR");
+    if (!d) return EXIT_FAILURE;
+    if (d->kind != Kind::CSR) { ERR("hipSpMVTilesCSR: handle is not CSR"); return EXIT_FAILURE; }
+    if (d->M == 0) return EXIT_SUCCESS;
+    if (d->NZ == 0) {                               // nothing to slice: y = 0
+        HIP_TRY(hipMemsetAsync(dY, 0, d->M * sizeof(double), S.stream));
+        if (S.sync) HIP_TRY(hipStreamSynchronize(S.stream));
+        return EXIT_SUCCESS;
+    }
+    if (!d->tiles && buildTiles(d)) return EXIT_FAILURE;
+    Launch L(dim3((unsigned)((d->M + 16383) / 16384)), dim3(1024));
+    if (enqueueTiles(d, dX, dY, S.stream)) { ERR("hipSpMVTilesCSR: launch failed"); return EXIT_FAILURE; }
+    return L.finish("hipSpMVTilesCSR");
 }
 
 int hipSpMVRowsELL(spmat* dMat, double* dX, CONFIG cfg, double* dY) {

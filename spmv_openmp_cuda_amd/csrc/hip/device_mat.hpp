@@ -25,6 +25,8 @@ constexpr uint64_t IRP32_LIMIT     = (1ull << 32) - 65536;
 
 enum class Kind : int { CSR = 0, ELL_ROWMAJOR = 1, ELL_COLMAJOR = 2 };
 
+struct TileFormat;          // column-sliced two-phase format, tiles.hip
+
 struct DevMat {
     uint32_t magic = 0x53504D56;    // 'SPMV'
     Kind     kind  = Kind::CSR;
@@ -42,7 +44,13 @@ struct DevMat {
     uint32_t  nBlk = 0;
     uint32_t  nLongBlk = 0;         // blocks that are a single row longer than STREAM_NNZ
     uint64_t  maxRowNnz = 0;
+    TileFormat* tiles = nullptr;    // built lazily by hipSpMVTilesCSR / spmvHipBuildTiles
 };
+
+int  buildTiles(DevMat* d);                                     // tiles.hip
+void freeTiles(TileFormat* t);
+int  enqueueTiles(DevMat* d, const double* x, double* y, hipStream_t stream);
+size_t tilesBytes(const DevMat* d);
 
 // Fold `blocks` workgroups into an (x, y) grid whose x extent keeps
 // x * threads < 2^32 (AQL grid_size is 32-bit work-items per dimension).

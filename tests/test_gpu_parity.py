@@ -49,6 +49,12 @@ def _cases():
     cases["ones"] = (10000, 300) + random_csr(rng, 10000, 300, np.ones(10000, dtype=int))
     # uniform 32/row
     cases["uniform32"] = (4096, 4096) + random_csr(rng, 4096, 4096, np.full(4096, 32))
+    # wide and tall enough for several 16 Ki-column slices and several row bins (tiles kernel)
+    Mw, Nw = 40000, 70000
+    lw = rng.integers(0, 12, size=Mw)
+    lw[123] = 30000
+    lw[39999] = 5000
+    cases["wide"] = (Mw, Nw) + random_csr(rng, Mw, Nw, lw)
     return cases
 
 
@@ -73,15 +79,19 @@ def _run(api, launcher, dmat, x, rows):
 @pytest.mark.parametrize("name", list(CASES))
 @pytest.mark.parametrize("launcher,variant,exact", [
     ("hipSpMVRowsCSR", 0, True), ("hipSpMVRowsCSR", 1, True),
-    ("hipSpMVWarpPerRowCSR", 0, False), ("hipSpMVWarpPerRowCSR", 1, False)])
+    ("hipSpMVWarpPerRowCSR", 0, False), ("hipSpMVWarpPerRowCSR", 1, False),
+    ("hipSpMVTilesCSR", -1, False)])
 def test_csr(api, oracle, name, launcher, variant, exact):
     M, N, IRP, JA, AS = CASES[name]
     x = _x(np.random.default_rng(7), N)
     y_ref = oracle.csr_serial(IRP, JA, AS, x)
     host = api.HostCSR(M, N, IRP, JA, AS)
     dmat = api.spMatCpyCSR(host)
-    api.set_variant(launcher, variant)
+    if variant >= 0:
+        api.set_variant(launcher, variant)
     y = _run(api, launcher, dmat, x, M)
+    if launcher == "hipSpMVTilesCSR" and JA.size:       # second call re-uses the built format
+        assert np.max(np.abs(_run(api, launcher, dmat, x, M) - y)) <= 1e-15    # arrival-order sums differ in the last bits
     dmat.free()
     assert not np.isnan(y).any(), "rows left unwritten (poison survived)"
     assert np.max(np.abs(y - y_ref), initial=0.0) <= GATE
@@ -148,7 +158,7 @@ def test_synth_device_matches_twin_and_oracle(api, oracle):
             assert (d[mask] > 0).all() and ja_ref.max() < w.N
             x = synth.make_x(w.N, w.cfg)
             y_ref = oracle.csr_serial_dev(irp.astype(np.uint32), ja_ref, as_ref, x)
-            for launcher, exact in (("hipSpMVRowsCSR", True), ("hipSpMVWarpPerRowCSR", False)):
+            for launcher, exact in (("hipSpMVRowsCSR", True), ("hipSpMVWarpPerRowCSR", False), ("hipSpMVTilesCSR", False)):
                 y = _run(api, launcher, dm, x, w.N)
                 assert np.max(np.abs(y - y_ref)) <= GATE
                 if exact:
@@ -190,7 +200,7 @@ def test_full_size_spot_checks(api, oracle, key):
                                   dm.buffers["JA"].ptr.value + 4 * b0, 4 * (b1 - b0))
         assert np.array_equal(ja_dev, ja)
         refs.append(oracle.csr_serial_dev((irp[r0:r1 + 1] - irp[r0]).astype(np.uint32), ja, as_, x))
-    for launcher, exact in (("hipSpMVWarpPerRowCSR", False), ("hipSpMVRowsCSR", True)):
+    for launcher, exact in (("hipSpMVWarpPerRowCSR", False), ("hipSpMVRowsCSR", True), ("hipSpMVTilesCSR", False)):
         dy.poison()
         api.spmv(launcher, dm, dx, dy)
         y = dy.down()
@@ -203,6 +213,9 @@ def test_full_size_spot_checks(api, oracle, key):
         dx2 = api.DeviceVector(w.N).up(2.0 * x)
         dy.poison()
         api.spmv(launcher, dm, dx2, dy)
-        assert np.array_equal(dy.down(), 2.0 * y)
+        if launcher == "hipSpMVTilesCSR":       # arrival-order sums: linear up to rounding only
+            assert np.max(np.abs(dy.down() - 2.0 * y)) <= 1e-15
+        else:
+            assert np.array_equal(dy.down(), 2.0 * y)
         dx2.free()
     dm.free()
