@@ -51,6 +51,8 @@ def parse():
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-extra", action="store_true", help="skip the secondary workloads measured at N=1")
     p.add_argument("--cpu-sample-nnz", type=int, default=100_000_000)
+    p.add_argument("--force-dist", action="store_true",
+                   help="run the multi-rank code path (process group, all-gather) even with --gpus 1; for rehearsal")
     return p.parse_args()
 
 
@@ -260,8 +262,12 @@ def main():
     world = args.gpus
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    if world > 1 or args.force_dist:
         assert int(os.environ.get("WORLD_SIZE", "1")) == world, "launch with torch.distributed.run --nproc-per-node N"
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         torch.cuda.set_device(local)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
     else:
@@ -280,7 +286,7 @@ def main():
     t_setup = time.perf_counter()
 
     extra = {}
-    if world == 1:
+    if world == 1 and not args.force_dist:
         res, ctx = measure_single(api, synth, torch, w, args.launcher, steps, warmup)
         log(f"{w.name} [{res['launcher']}]: {res['gflops']:.1f} GFLOP/s  kernel {res['kernel_ms_avg']:.3f} ms  "
             f"{res['hbm_gbps']:.0f} GB/s = {100 * res['hbm_frac']:.1f}% of 8 TB/s   (setup {time.perf_counter() - t_setup:.1f}s)")

@@ -74,6 +74,11 @@ int spMatCpyCSR(spmat* host, spmat* dMat);
  * are stored in elements as the reference does (cudaUtils.cu:81-83). */
 int spMatCpyELL(spmat* host, spmat* dMat);
 int spMatCpyELLTransposed(spmat* hostT, spmat* dMat);
+/* Device-side CSR -> ELL of an uploaded matrix (slots = its longest row, row
+ * lengths kept): transposed = 0 gives the row-major handle spMatCpyELL(ell)
+ * would, 1 the column-major one of ellTranspose + spMatCpyELL.  The host-side
+ * ELL size guard (parser.c:223-232) is not applied here. */
+int spmvHipCsrToEll(spmat* dCsr, int transposed, spmat* dEll);
 /* Release the device arrays behind a handle (cudaUtils.h:70-78). */
 int hipFreeSpmat(spmat* dMat);
 

@@ -50,6 +50,7 @@ _sigs = {
     "spMatCpyELL": ([C.POINTER(spmat), C.POINTER(spmat)], _i),
     "spMatCpyELLTransposed": ([C.POINTER(spmat), C.POINTER(spmat)], _i),
     "hipFreeSpmat": ([C.POINTER(spmat)], _i),
+    "spmvHipCsrToEll": ([C.POINTER(spmat), _i, C.POINTER(spmat)], _i),
     "spmvHipAdoptCSR": ([C.POINTER(spmat), C.c_ulong, C.c_ulong, C.c_ulong, _vp, _i, _vp, _vp, _vp], _i),
     "hipSpMVRowsCSR": (_SPMV_ARGS, _i), "hipSpMVWarpPerRowCSR": (_SPMV_ARGS, _i),
     "hipSpMVTilesCSR": (_SPMV_ARGS, _i), "spmvHipBuildTiles": ([C.POINTER(spmat)], _i),
@@ -300,6 +301,13 @@ def spMatCpyELL(host: HostELL) -> DeviceMatrix:
     d = DeviceMatrix()
     _check(lib.spMatCpyELL(C.byref(host.struct), C.byref(d.handle)), "spMatCpyELL")
     d.rows = host.rows
+    return d
+
+
+def csr_to_ell_device(dcsr: DeviceMatrix, transposed: bool) -> DeviceMatrix:
+    d = DeviceMatrix()
+    _check(lib.spmvHipCsrToEll(C.byref(dcsr.handle), 1 if transposed else 0, C.byref(d.handle)), "spmvHipCsrToEll")
+    d.rows = dcsr.rows
     return d
 
 

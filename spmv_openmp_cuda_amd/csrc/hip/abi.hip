@@ -149,6 +149,25 @@ __global__ void fill64_kernel(uint64_t* p, size_t n, uint64_t v) {
     for (; i < n; i += stride) p[i] = v;
 }
 
+// device-side CSR -> ELL (row-major [rows][pitch] or column-major [slots][pitch]); one wavefront per row
+template <typename I>
+__global__ __launch_bounds__(256) void csr_to_ell_kernel(uint32_t M, uint32_t K, size_t pitch, int colMajor,
+                                                         const I* __restrict__ IRP, const uint32_t* __restrict__ JA,
+                                                         const double* __restrict__ AS, uint32_t* __restrict__ EJ,
+                                                         double* __restrict__ EA, uint32_t* __restrict__ RL) {
+    const uint64_t row = linear_block() * 4 + threadIdx.x / 64;
+    if (row >= M) return;
+    const uint32_t lane = threadIdx.x % 64;
+    const I b = IRP[row];
+    const uint32_t len = (uint32_t)(IRP[row + 1] - b);
+    if (lane == 0) RL[row] = len;
+    for (uint32_t c = lane; c < K; c += 64) {
+        const size_t at = colMajor ? (size_t)c * pitch + row : (size_t)row * pitch + c;
+        EJ[at] = c < len ? JA[b + c] : 0u;          // padding {0, 0.0} like the loader's calloc
+        EA[at] = c < len ? AS[b + c] : 0.0;
+    }
+}
+
 template <bool SEQ>
 static void launchStream(DevMat* d, double* x, double* y) {
     if (d->irpBytes == 4)
@@ -409,6 +428,33 @@ int spmvHipAdoptCSR(spmat* dst, ulong M, ulong N, ulong NZ, const void* dIRP, in
 
 int spMatCpyELL(spmat* m, spmat* dst) { return ellUpload(m, dst, m && m->dev == SPMAT_TAG_ELL_TRANSPOSED); }
 int spMatCpyELLTransposed(spmat* m, spmat* dst) { return ellUpload(m, dst, true); }
+
+int spmvHipCsrToEll(spmat* dCsr, int transposed, spmat* dEll) {
+    DevMat* c = descOf(dCsr, "spmvHipCsrToEll");
+    if (!c || !dEll) return EXIT_FAILURE;
+    if (c->kind != Kind::CSR) { ERR("spmvHipCsrToEll: source handle is not CSR"); return EXIT_FAILURE; }
+    const uint64_t K = c->maxRowNnz, rows = c->M;
+    DevMat* d = new DevMat;
+    d->kind = transposed ? Kind::ELL_COLMAJOR : Kind::ELL_ROWMAJOR;
+    d->M = rows; d->N = c->N; d->NZ = c->NZ; d->K = K;
+    d->pitch = transposed ? (rows + 63) / 64 * 64 : (K + 15) / 16 * 16;
+    const size_t cells = std::max<size_t>((transposed ? K : rows) * d->pitch, 1);
+    if (!hipOk(hipMalloc(&d->JA, cells * sizeof(uint32_t)), "hipMalloc ELL JA") ||
+        !hipOk(hipMalloc(&d->AS, cells * sizeof(double)), "hipMalloc ELL AS") ||
+        !hipOk(hipMalloc(&d->RL, std::max<size_t>(rows, 1) * sizeof(uint32_t)), "hipMalloc ELL RL") ||
+        !hipOk(hipMemsetAsync(d->JA, 0, cells * sizeof(uint32_t), S.stream), "memset") ||
+        !hipOk(hipMemsetAsync(d->AS, 0, cells * sizeof(double), S.stream), "memset")) { freeDesc(d); return EXIT_FAILURE; }
+    if (rows) {
+        const dim3 grid = grid2d((rows + 3) / 4, 256);
+        if (c->irpBytes == 4) hipLaunchKernelGGL((csr_to_ell_kernel<uint32_t>), grid, dim3(256), 0, S.stream, (uint32_t)rows, (uint32_t)K, d->pitch, transposed, static_cast<const uint32_t*>(c->IRP), c->JA, c->AS, d->JA, d->AS, d->RL);
+        else                  hipLaunchKernelGGL((csr_to_ell_kernel<uint64_t>), grid, dim3(256), 0, S.stream, (uint32_t)rows, (uint32_t)K, d->pitch, transposed, static_cast<const uint64_t*>(c->IRP), c->JA, c->AS, d->JA, d->AS, d->RL);
+    }
+    if (!hipOk(hipGetLastError(), "csr_to_ell launch") || !hipOk(hipStreamSynchronize(S.stream), "csr_to_ell")) { freeDesc(d); return EXIT_FAILURE; }
+    // handle fields follow the reference's conventions (transposed: M = slots, MAX_ROW_NZ = rows)
+    if (transposed) publish(dEll, d, K, rows, c->NZ, rows);
+    else            publish(dEll, d, rows, c->N, c->NZ, K);
+    return EXIT_SUCCESS;
+}
 
 int hipFreeSpmat(spmat* h) {
     if (!h || !h->dev) return EXIT_SUCCESS;

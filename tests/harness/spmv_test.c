@@ -140,7 +140,9 @@ int main(int argc, char** argv) {
             hprintsf("@computing SpMV   with func: CUDA CSR %u at:%p\n", f, (void*)SpmvCUDA_CSRFuncs[f]);
             if (testSpMVImplHip(SpmvCUDA_CSRFuncs[f], &dMat, mat->M, dVect, dOutV, outV, oracleOut, &avg)) goto _free;
             printf("#tight CSR %u\tmax|dy|/sum|a x|:%le\n", f, oracleScaledError(matCSR, vector, oracleOut, outV));
-            perfLine(f ? "HIP CSR 1" : "HIP CSR 0", bytesCsr, mat->NZ, avg);
+            char tagc[32];
+            snprintf(tagc, sizeof tagc, "HIP CSR %u", f);
+            perfLine(tagc, bytesCsr, mat->NZ, avg);
         }
         hipFreeSpmat(&dMat);
         /* ---- ELL */

@@ -219,3 +219,24 @@ def test_full_size_spot_checks(api, oracle, key):
             assert np.array_equal(dy.down(), 2.0 * y)
         dx2.free()
     dm.free()
+
+
+@pytest.mark.parametrize("name", ["irregular", "cage4-shaped", "empty-rows", "uniform32"])
+def test_device_csr_to_ell(api, oracle, name):
+    """spmvHipCsrToEll (device-side conversion) gives the same results as host to_ell/ellTranspose + spMatCpyELL."""
+    M, N, IRP, JA, AS = CASES[name]
+    x = _x(np.random.default_rng(11), N)
+    y_ref = oracle.csr_serial(IRP, JA, AS, x)
+    dcsr = api.spMatCpyCSR(api.HostCSR(M, N, IRP, JA, AS))
+    for transposed, launcher in ((True, "hipSpMVRowsELL"), (False, "hipSpMVRowsELLNNTransposed"),
+                                 (False, "hipSpMVWarpsPerRowELLNTrasposed")):
+        dell = api.csr_to_ell_device(dcsr, transposed)
+        for rl in (1, 0):
+            api.lib.spmvHipSetEllRowLens(rl)
+            y = _run(api, launcher, dell, x, M)
+            assert not np.isnan(y).any() and np.max(np.abs(y - y_ref), initial=0.0) <= GATE
+            if launcher != "hipSpMVWarpsPerRowELLNTrasposed":
+                assert np.array_equal(y, y_ref + 0.0)
+        dell.free()
+    api.lib.spmvHipSetEllRowLens(1)
+    dcsr.free()

@@ -20,7 +20,7 @@ HARNESS = os.path.join(ROOT, "tests", "harness", "test_SpMV_HIP.elf")
 
 
 @pytest.mark.parametrize("name", NAMES)
-@pytest.mark.parametrize("mode", ["CUDA_CSR_ROWS", "CUDA_CSR_ROWS_WARP", "CUDA_ELL_ROWS",
+@pytest.mark.parametrize("mode", ["CUDA_CSR_ROWS", "CUDA_CSR_ROWS_WARP", "HIP_CSR_TILES", "CUDA_ELL_ROWS",
                                   "HIP_ELL_ROWS_NN_TRANSPOSED", "CUDA_ELL_ROWS_WARP_NN_TRANSPOSED"])
 def test_cli_against_reference_cli_output(name, mode):
     g = load_golden(name)
@@ -51,7 +51,7 @@ def test_harness_all_implementations_pass(name):
                        capture_output=True, text=True, timeout=300, env=dict(os.environ, OMP_NUM_THREADS="4"))
     assert r.returncode == 0, r.stdout + r.stderr
     out = r.stdout
-    assert out.count("cudaBlockSize:") == 5 and out.count("threadNum:") == 3
+    assert out.count("cudaBlockSize:") == 6 and out.count("threadNum:") == 3     # 3 CSR + 3 ELL launchers, 3 OpenMP
     assert "AVG_TIMES_ITERATION:25" in out and "MAX_ROW_NZ" in out and "omp sched gather:" in out
 
 
