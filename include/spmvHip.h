@@ -124,9 +124,13 @@ int spmvHipEnqueueCSR(spmat* dMat, int warpPerRow, double* dX, double* dY, void*
  *   hipSpMVRowsCSR        0 = one thread walks its row in global memory ("scalar")
  *                         1 = LDS-stream: coalesced span load, one thread sums its row
  *                             in ascending-j order (bit-identical to the serial oracle)
+ *                         2 = (default) same, second generation: scalar-loaded block
+ *                             table, row pointers staged in LDS, long rows first,
+ *                             XCD-contiguous block order
  *   hipSpMVWarpPerRowCSR  0 = one wavefront per row, __shfl_down tree
  *                         1 = adaptive: LDS segmented reduction for short rows,
  *                             wavefront-/workgroup-per-row for long ones
+ *                         2 = (default) same, second generation
  * Returns EXIT_FAILURE for an unknown (launcher, variant). */
 int spmvHipSetVariant(const char* launcher, int variant);
 /* Use the RL array for ELL early exit (1, default when RL was uploaded) or walk

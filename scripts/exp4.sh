@@ -1,0 +1,3 @@
+for wl in c3n c3b; do for l in hipSpMVWarpPerRowCSR hipSpMVRowsCSR hipSpMVTilesCSR; do
+ echo "== $wl $l"; timeout -k 10 300 python bench.py --workload $wl --launcher $l --no-extra --no-cpu-baseline --steps 10 2>&1 | grep "^\[bench\]"
+done; done

@@ -20,8 +20,8 @@ struct State {
     int         dev = 0;
     hipStream_t stream = nullptr;
     bool        sync = true;
-    int         variantRowsCSR = 1;     // 0 scalar, 1 LDS-stream SEQ
-    int         variantWarpCSR = 1;     // 0 wavefront-per-row, 1 adaptive LDS-stream VEC
+    int         variantRowsCSR = 2;     // 0 scalar, 1 LDS-stream SEQ (first generation), 2 second generation
+    int         variantWarpCSR = 2;     // 0 wavefront-per-row, 1 LDS-stream VEC (first generation), 2 second generation
     int         variantRowsEllNT = 0;
     bool        ellRowLens = true;
     double      lastSeconds = 0;
@@ -69,6 +69,48 @@ void buildRowBlocks(const I* IRP, uint64_t M, std::vector<uint32_t>& blk, uint32
     for (uint64_t i = 0; i < M; ++i) maxRow = std::max<uint64_t>(maxRow, (uint64_t)IRP[i + 1] - (uint64_t)IRP[i]);
 }
 
+// Block table of csr_stream2_kernel: rows packed while nnz <= STREAM_NNZ and rows <= STREAM2_MAX_ROWS;
+// a longer row is a block of its own, flagged, and all such blocks come first (longest first) so that
+// their serial tails overlap the rest of the grid.
+template <typename I>
+int buildRowBlocks2(DevMat* d, const I* IRP, uint64_t M) {
+    std::vector<uint4> info, longs;
+    std::vector<uint64_t> base, longBase;
+    info.reserve(M / 64 + 2); base.reserve(M / 64 + 2);
+    uint64_t r = 0;
+    while (r < M) {
+        const uint64_t start = IRP[r];
+        uint64_t e = r;
+        while (e < M && (uint64_t)IRP[e + 1] - start <= (uint64_t)STREAM_NNZ && e - r < STREAM2_MAX_ROWS) ++e;
+        if (e == r) {
+            const uint64_t len = (uint64_t)IRP[r + 1] - start;
+            if (len >= (1ull << 32)) { ERR("a single row with %lu entries is not supported", (unsigned long)len); return EXIT_FAILURE; }
+            longs.push_back(make_uint4((uint32_t)r, 1u, (uint32_t)len, 1u));
+            longBase.push_back(start);
+            e = r + 1;
+        } else {
+            info.push_back(make_uint4((uint32_t)r, (uint32_t)(e - r), (uint32_t)((uint64_t)IRP[e] - start), 0u));
+            base.push_back(start);
+        }
+        r = e;
+    }
+    std::vector<size_t> order(longs.size());
+    for (size_t i = 0; i < order.size(); ++i) order[i] = i;
+    std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) { return longs[a].z > longs[b].z; });
+    std::vector<uint4> allInfo; std::vector<uint64_t> allBase;
+    allInfo.reserve(longs.size() + info.size()); allBase.reserve(longs.size() + info.size());
+    for (size_t i : order) { allInfo.push_back(longs[i]); allBase.push_back(longBase[i]); }
+    allInfo.insert(allInfo.end(), info.begin(), info.end());
+    allBase.insert(allBase.end(), base.begin(), base.end());
+    d->nBlk2 = (uint32_t)allInfo.size();
+    d->nLong2 = (uint32_t)longs.size();
+    HIP_TRY(hipMalloc(&d->blkInfo, std::max<size_t>(allInfo.size(), 1) * sizeof(uint4)));
+    HIP_TRY(hipMalloc(&d->blkBase, std::max<size_t>(allBase.size(), 1) * sizeof(uint64_t)));
+    HIP_TRY(hipMemcpy(d->blkInfo, allInfo.data(), allInfo.size() * sizeof(uint4), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(d->blkBase, allBase.data(), allBase.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
+    return EXIT_SUCCESS;
+}
+
 int uploadRowBlocks(DevMat* d, const std::vector<uint32_t>& blk) {
     d->nBlk = (uint32_t)blk.size() - 1;
     HIP_TRY(hipMalloc(&d->blkRow, blk.size() * sizeof(uint32_t)));
@@ -81,7 +123,7 @@ void freeDesc(DevMat* d) {
     if (d->owns) {
         (void)hipFree(d->IRP); (void)hipFree(d->JA); (void)hipFree(d->AS); (void)hipFree(d->RL);
     }
-    (void)hipFree(d->blkRow);
+    (void)hipFree(d->blkRow); (void)hipFree(d->blkInfo); (void)hipFree(d->blkBase);
     freeTiles(d->tiles);
     d->magic = 0;
     delete d;
@@ -178,6 +220,16 @@ static void launchStream(DevMat* d, double* x, double* y) {
                            d->nBlk, d->blkRow, static_cast<const uint64_t*>(d->IRP), d->JA, d->AS, x, y);
 }
 
+
+template <bool SEQ>
+static void launchStream2(DevMat* d, double* x, double* y) {
+    if (d->irpBytes == 4)
+        hipLaunchKernelGGL((csr_stream2_kernel<uint32_t, SEQ>), grid2d(d->nBlk2, WG_THREADS), dim3(WG_THREADS), 0, S.stream,
+                           d->nBlk2, d->nLong2, d->blkInfo, d->blkBase, static_cast<const uint32_t*>(d->IRP), d->JA, d->AS, x, y);
+    else
+        hipLaunchKernelGGL((csr_stream2_kernel<uint64_t, SEQ>), grid2d(d->nBlk2, WG_THREADS), dim3(WG_THREADS), 0, S.stream,
+                           d->nBlk2, d->nLong2, d->blkInfo, d->blkBase, static_cast<const uint64_t*>(d->IRP), d->JA, d->AS, x, y);
+}
 
 template <int G>
 static void launchEllGroup(DevMat* d, bool rl, dim3 grid, dim3 block, double* x, double* y) {
@@ -323,8 +375,8 @@ int spmvHipDeviceSynchronize(void) { HIP_TRY(hipDeviceSynchronize()); return EXI
 
 int spmvHipSetVariant(const char* launcher, int variant) {
     if (!launcher) return EXIT_FAILURE;
-    if (!strcmp(launcher, "hipSpMVRowsCSR") && (variant == 0 || variant == 1)) { S.variantRowsCSR = variant; return EXIT_SUCCESS; }
-    if (!strcmp(launcher, "hipSpMVWarpPerRowCSR") && (variant == 0 || variant == 1)) { S.variantWarpCSR = variant; return EXIT_SUCCESS; }
+    if (!strcmp(launcher, "hipSpMVRowsCSR") && variant >= 0 && variant <= 2) { S.variantRowsCSR = variant; return EXIT_SUCCESS; }
+    if (!strcmp(launcher, "hipSpMVWarpPerRowCSR") && variant >= 0 && variant <= 2) { S.variantWarpCSR = variant; return EXIT_SUCCESS; }
     ERR("spmvHipSetVariant: unknown (%s, %d)", launcher, variant);
     return EXIT_FAILURE;
 }
@@ -396,6 +448,7 @@ int spMatCpyCSR(spmat* m, spmat* dst) {
         std::vector<uint32_t> blk;
         buildRowBlocks(m->IRP, m->M, blk, d->nLongBlk, d->maxRowNnz);
         rc = uploadRowBlocks(d, blk);
+        if (!rc) rc = buildRowBlocks2(d, m->IRP, m->M);
     }
     if (rc) { freeDesc(d); return EXIT_FAILURE; }
     publish(dst, d, m->M, m->N, m->NZ, 0);
@@ -419,9 +472,10 @@ int spmvHipAdoptCSR(spmat* dst, ulong M, ulong N, ulong NZ, const void* dIRP, in
     d->M = M; d->N = N; d->NZ = NZ; d->irpBytes = irpBytes;
     d->IRP = const_cast<void*>(dIRP); d->JA = const_cast<uint32_t*>(dJA); d->AS = const_cast<double*>(dAS);
     std::vector<uint32_t> blk;
-    if (irpBytes == 4) buildRowBlocks(static_cast<const uint32_t*>(hIRP), M, blk, d->nLongBlk, d->maxRowNnz);
-    else               buildRowBlocks(static_cast<const uint64_t*>(hIRP), M, blk, d->nLongBlk, d->maxRowNnz);
-    if (uploadRowBlocks(d, blk)) { freeDesc(d); return EXIT_FAILURE; }
+    int rc2;
+    if (irpBytes == 4) { buildRowBlocks(static_cast<const uint32_t*>(hIRP), M, blk, d->nLongBlk, d->maxRowNnz); rc2 = buildRowBlocks2(d, static_cast<const uint32_t*>(hIRP), M); }
+    else               { buildRowBlocks(static_cast<const uint64_t*>(hIRP), M, blk, d->nLongBlk, d->maxRowNnz); rc2 = buildRowBlocks2(d, static_cast<const uint64_t*>(hIRP), M); }
+    if (rc2 || uploadRowBlocks(d, blk)) { freeDesc(d); return EXIT_FAILURE; }
     publish(dst, d, M, N, NZ, 0);
     return EXIT_SUCCESS;
 }
@@ -473,7 +527,7 @@ int spmvHipEnqueueCSR(spmat* dMat, int warpPerRow, double* dX, double* dY, void*
     if (d->M == 0) return EXIT_SUCCESS;
     hipStream_t keep = S.stream;
     S.stream = static_cast<hipStream_t>(stream);
-    if (warpPerRow) launchStream<false>(d, dX, dY); else launchStream<true>(d, dX, dY);
+    if (warpPerRow) launchStream2<false>(d, dX, dY); else launchStream2<true>(d, dX, dY);
     S.stream = keep;
     HIP_TRY(hipGetLastError());
     return EXIT_SUCCESS;
@@ -493,8 +547,13 @@ int hipSpMVRowsCSR(spmat* dMat, double* dX, CONFIG cfg, double* dY) {
         else                  hipLaunchKernelGGL((csr_scalar_kernel<uint64_t>), grid, block, 0, S.stream, M, static_cast<const uint64_t*>(d->IRP), d->JA, d->AS, dX, dY);
         return L.finish("hipSpMVRowsCSR");
     }
-    Launch L(grid2d(d->nBlk, WG_THREADS), dim3(WG_THREADS));
-    launchStream<true>(d, dX, dY);
+    if (S.variantRowsCSR == 1) {
+        Launch L(grid2d(d->nBlk, WG_THREADS), dim3(WG_THREADS));
+        launchStream<true>(d, dX, dY);
+        return L.finish("hipSpMVRowsCSR");
+    }
+    Launch L(grid2d(d->nBlk2, WG_THREADS), dim3(WG_THREADS));
+    launchStream2<true>(d, dX, dY);
     return L.finish("hipSpMVRowsCSR");
 }
 
@@ -513,8 +572,13 @@ int hipSpMVWarpPerRowCSR(spmat* dMat, double* dX, CONFIG cfg, double* dY) {
         else                  hipLaunchKernelGGL((csr_vector_kernel<uint64_t>), grid, block, 0, S.stream, M, static_cast<const uint64_t*>(d->IRP), d->JA, d->AS, dX, dY);
         return L.finish("hipSpMVWarpPerRowCSR");
     }
-    Launch L(grid2d(d->nBlk, WG_THREADS), dim3(WG_THREADS));
-    launchStream<false>(d, dX, dY);
+    if (S.variantWarpCSR == 1) {
+        Launch L(grid2d(d->nBlk, WG_THREADS), dim3(WG_THREADS));
+        launchStream<false>(d, dX, dY);
+        return L.finish("hipSpMVWarpPerRowCSR");
+    }
+    Launch L(grid2d(d->nBlk2, WG_THREADS), dim3(WG_THREADS));
+    launchStream2<false>(d, dX, dY);
     return L.finish("hipSpMVWarpPerRowCSR");
 }
 

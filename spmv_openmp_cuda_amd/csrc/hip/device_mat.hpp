@@ -44,6 +44,10 @@ struct DevMat {
     uint32_t  nBlk = 0;
     uint32_t  nLongBlk = 0;         // blocks that are a single row longer than STREAM_NNZ
     uint64_t  maxRowNnz = 0;
+    // second-generation block table (csr_stream2_kernel): long rows first, then row order
+    uint4*    blkInfo = nullptr;    // {first row, #rows, #nnz, long-row flag}
+    uint64_t* blkBase = nullptr;    // nnz offset of the block
+    uint32_t  nBlk2 = 0, nLong2 = 0;
     TileFormat* tiles = nullptr;    // built lazily by hipSpMVTilesCSR / spmvHipBuildTiles
 };
 

@@ -211,6 +211,148 @@ __global__ __launch_bounds__(WG_THREADS) void csr_stream_kernel(
     }
 }
 
+// LDS-stream kernel, second generation (default).  Same algorithm as csr_stream_kernel with the
+// latency chain shortened:
+//   * the block table holds {first row, #rows, #nnz} and the block's nnz offset, read with scalar
+//     loads -> no dependent IRP[r0] / IRP[r1] round trips before the stream can start;
+//   * the block's row pointers are loaded together with the AS/JA span and parked in LDS as
+//     16-bit local offsets -> the reduction phase never waits on global memory;
+//   * blocks are ordered long rows first (their serial tail overlaps the rest), then by row;
+//     the row-ordered part is dealt to the 8 XCDs in contiguous ranges (workgroups b, b+8, ...
+//     share an XCD) so that neighbouring rows -- and their x window -- meet in one L2.
+// (An LDS x tile -- staging a block's 2 Ki-column window of x in LDS and gathering from LDS -- was
+//  built and measured: on a +-512 band it is SLOWER, 0.80 vs 0.56 ms, because the window is reloaded
+//  per 2048-nnz block, costs a second barrier and halves occupancy, while the L1-resident gather it
+//  replaces already runs at ~1 lane/clk/CU.  Not kept)
+constexpr uint32_t STREAM2_MAX_ROWS = 512;
+
+template <typename I, bool SEQ>
+__global__ __launch_bounds__(WG_THREADS) void csr_stream2_kernel(
+    uint32_t nBlk, uint32_t nLong, const uint4* __restrict__ blkInfo, const uint64_t* __restrict__ blkBase,
+    const I* __restrict__ IRP, const uint32_t* __restrict__ JA,
+    const double* __restrict__ AS, const double* __restrict__ x, double* __restrict__ y) {
+    __shared__ double   prod[STREAM_NNZ];
+    __shared__ uint16_t rowOff[STREAM2_MAX_ROWS + 1];
+    __shared__ double   wpart[WG_THREADS / WAVE];
+
+    const uint32_t tid = threadIdx.x;
+    uint64_t blk = linear_block();
+    if (blk >= nBlk) return;
+    if (blk >= nLong) {
+        // XCD-contiguous deal of the row-ordered blocks
+        // (bijection of [0,n): stripe x = q % 8 gets the a or a+1 consecutive blocks starting at x*a + min(x, rem))
+        const uint64_t q = blk - nLong, n = nBlk - nLong;
+        const uint64_t a = n / 8, rem = n % 8, xcd = q % 8;
+        blk = nLong + xcd * a + (xcd < rem ? xcd : rem) + q / 8;
+    }
+    const uint4 info = blkInfo[blk];
+    const uint32_t r0 = info.x, R = info.y, n = info.z;
+    const uint64_t base = blkBase[blk];
+
+    if (info.w) {
+        // ---- long row (single row of n > 2048 entries)
+        const uint64_t end = base + n;
+        if (SEQ) {
+            double acc = 0;
+            for (uint64_t c = base; c < end; c += STREAM_NNZ) {
+                const uint32_t cn = (uint32_t)(end - c < (uint64_t)STREAM_NNZ ? end - c : (uint64_t)STREAM_NNZ);
+#pragma unroll
+                for (int u = 0; u < STREAM_UNROLL; ++u) {
+                    const uint32_t k = tid + u * WG_THREADS;
+                    if (k < cn) prod[k] = stream_load(AS + c + k) * x[stream_load(JA + c + k)];
+                }
+                __syncthreads();
+                if (tid == 0)
+                    for (uint32_t j = 0; j < cn; ++j) acc += prod[j];
+                __syncthreads();
+            }
+            if (tid == 0) y[r0] = acc;
+            return;
+        }
+        double acc0 = 0, acc1 = 0, acc2 = 0, acc3 = 0;
+        uint64_t j = base + tid;
+        for (; j + 3 * WG_THREADS < end; j += 4 * WG_THREADS) {
+            const uint32_t c0 = stream_load(JA + j), c1 = stream_load(JA + j + WG_THREADS),
+                           c2 = stream_load(JA + j + 2 * WG_THREADS), c3 = stream_load(JA + j + 3 * WG_THREADS);
+            const double a0 = stream_load(AS + j), a1 = stream_load(AS + j + WG_THREADS),
+                         a2 = stream_load(AS + j + 2 * WG_THREADS), a3 = stream_load(AS + j + 3 * WG_THREADS);
+            acc0 += a0 * x[c0]; acc1 += a1 * x[c1]; acc2 += a2 * x[c2]; acc3 += a3 * x[c3];
+        }
+        for (; j < end; j += WG_THREADS) acc0 += stream_load(AS + j) * x[stream_load(JA + j)];
+        double acc = wave_sum((acc0 + acc1) + (acc2 + acc3));
+        if (tid % WAVE == 0) wpart[tid / WAVE] = acc;
+        __syncthreads();
+        if (tid == 0) {
+            double s = wpart[0];
+#pragma unroll
+            for (int w = 1; w < WG_THREADS / WAVE; ++w) s += wpart[w];
+            y[r0] = s;
+        }
+        return;
+    }
+
+    // ---- 1. span + row pointers in flight together
+    {
+        uint32_t col[STREAM_UNROLL];
+        double   val[STREAM_UNROLL];
+#pragma unroll
+        for (int u = 0; u < STREAM_UNROLL; ++u) {
+            const uint32_t k = tid + u * WG_THREADS;
+            const bool in = k < n;
+            col[u] = in ? stream_load(JA + base + k) : 0u;
+            val[u] = in ? stream_load(AS + base + k) : 0.0;
+        }
+        // rows r0 .. r0+R (R <= 512): two row pointers per lane, the closing one is base+n
+        uint32_t rp0 = 0, rp1 = 0;
+        if (tid < R) rp0 = (uint32_t)((uint64_t)IRP[r0 + tid] - base);
+        if (tid + WG_THREADS < R) rp1 = (uint32_t)((uint64_t)IRP[r0 + tid + WG_THREADS] - base);
+        double xv[STREAM_UNROLL];
+#pragma unroll
+        for (int u = 0; u < STREAM_UNROLL; ++u) xv[u] = x[col[u]];
+        if (tid < R) rowOff[tid] = (uint16_t)rp0;
+        if (tid + WG_THREADS < R) rowOff[tid + WG_THREADS] = (uint16_t)rp1;
+        if (tid == 0) rowOff[R] = (uint16_t)n;
+#pragma unroll
+        for (int u = 0; u < STREAM_UNROLL; ++u) {
+            const uint32_t k = tid + u * WG_THREADS;
+            if (k < n) prod[k] = val[u] * xv[u];
+        }
+    }
+    __syncthreads();
+
+    // ---- 2. per-row reduction, everything in LDS
+    if (SEQ) {
+        for (uint32_t rr = tid; rr < R; rr += WG_THREADS) {
+            const uint32_t s = rowOff[rr], e = rowOff[rr + 1];
+            double acc = 0;
+            for (uint32_t j = s; j < e; ++j) acc += prod[j];
+            y[r0 + rr] = acc;
+        }
+    } else {
+        int L = 1;
+        while (L < WAVE && 2u * L * R <= (uint32_t)WG_THREADS) L <<= 1;
+        const uint32_t rowsPerPass = WG_THREADS / L;
+        const uint32_t g = tid / L, l = tid % L;
+        const uint32_t passes = (R + rowsPerPass - 1) / rowsPerPass;
+        for (uint32_t p = 0; p < passes; ++p) {
+            const uint32_t rr = p * rowsPerPass + g;
+            const bool live = rr < R;
+            uint32_t s = 0, e = 0;
+            if (live) { s = rowOff[rr]; e = rowOff[rr + 1]; }
+            double acc = 0;
+            for (uint32_t j = s + l; j < e; j += L) acc += prod[j];
+            acc = group_sum_rt(acc, L);
+            if (live && l == 0) y[r0 + rr] = acc;
+        }
+    }
+}
+
+// (A persistent, software-pipelined form -- fixed grid, next block's span prefetched into a second
+//  register set while the current block is gathered and reduced -- was built and measured: 102 VGPRs
+//  -> 4 workgroups/CU, and slower everywhere (band 512: 0.83 vs 0.57 ms; serial-order variant 2.8 ms
+//  because long rows pin their workgroup).  With 8 resident workgroups per CU the hardware scheduler
+//  already overlaps the phases of different blocks.  Not kept)
+
 // ----------------------------------------------------------------------------------- ELL
 // Column-major ("transposed") + pitched, one thread per row: lane i of a wave
 // reads element i of a 512-byte line in every slot.  USE_RL = stop at the row's

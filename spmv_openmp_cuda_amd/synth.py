@@ -42,6 +42,8 @@ WORKLOADS = {
     # cache-friendly counterparts (columns within +-2^14 of the row)
     "c2b": Workload("c2b-uniform-1M-32-band", 1_000_000, 32_000_000, "uniform", cfg=2, band=1 << 14),
     "c3b": Workload("c3b-powerlaw-10M-200M-band", 10_000_000, 200_000_000, "powerlaw", cfg=3, band=1 << 14),
+    # narrow band (x window of a row block fits L1/LDS): the kernel-bound regime
+    "c3n": Workload("c3n-powerlaw-10M-200M-band512", 10_000_000, 200_000_000, "powerlaw", cfg=3, band=512),
     # small shapes for tests
     "tiny": Workload("tiny-powerlaw-20k", 20_000, 400_000, "powerlaw", max_row=5000, cfg=9),
     "tinyu": Workload("tiny-uniform-4k-32", 4096, 4096 * 32, "uniform", cfg=8),

@@ -49,6 +49,16 @@ def _cases():
     cases["ones"] = (10000, 300) + random_csr(rng, 10000, 300, np.ones(10000, dtype=int))
     # uniform 32/row
     cases["uniform32"] = (4096, 4096) + random_csr(rng, 4096, 4096, np.full(4096, 32))
+    # banded: every row block's columns fit the 2 Ki-column LDS x tile (incl. the clipped edges)
+    Mb = 6000
+    lb = rng.integers(1, 30, size=Mb)
+    IRPb = np.zeros(Mb + 1, dtype=np.uint64)
+    IRPb[1:] = np.cumsum(lb)
+    JAb = np.empty(int(IRPb[-1]), dtype=np.uint64)
+    for r in range(Mb):
+        lo, hi = max(0, r - 300), min(Mb, r + 300)
+        JAb[int(IRPb[r]):int(IRPb[r + 1])] = np.sort(rng.choice(np.arange(lo, hi), size=int(lb[r]), replace=False))
+    cases["banded"] = (Mb, Mb, IRPb, JAb, rng.uniform(-1, 1, size=JAb.size))
     # wide and tall enough for several 16 Ki-column slices and several row bins (tiles kernel)
     Mw, Nw = 40000, 70000
     lw = rng.integers(0, 12, size=Mw)
@@ -78,8 +88,8 @@ def _run(api, launcher, dmat, x, rows):
 
 @pytest.mark.parametrize("name", list(CASES))
 @pytest.mark.parametrize("launcher,variant,exact", [
-    ("hipSpMVRowsCSR", 0, True), ("hipSpMVRowsCSR", 1, True),
-    ("hipSpMVWarpPerRowCSR", 0, False), ("hipSpMVWarpPerRowCSR", 1, False),
+    ("hipSpMVRowsCSR", 0, True), ("hipSpMVRowsCSR", 1, True), ("hipSpMVRowsCSR", 2, True),
+    ("hipSpMVWarpPerRowCSR", 0, False), ("hipSpMVWarpPerRowCSR", 1, False), ("hipSpMVWarpPerRowCSR", 2, False),
     ("hipSpMVTilesCSR", -1, False)])
 def test_csr(api, oracle, name, launcher, variant, exact):
     M, N, IRP, JA, AS = CASES[name]
