@@ -1,16 +1,21 @@
 """Row-block sharding of y = A.x across the GPUs of one node.
 
 The reference is single-GPU; this part is new.  Rows are independent, so the
-matrix is cut into `world` contiguous row blocks balanced by nnz (boundaries on
-the IRP prefix sum), x is replicated, every rank computes its block and the
-ranks all-gather y so that each ends with the full vector.  One exchange step,
-one collective: an all-gather over RCCL/xGMI (gloo in the CPU tests).
+matrix is cut into contiguous row blocks balanced by nnz (boundaries on the IRP
+prefix sum), x is replicated, every rank computes its rows and the ranks
+all-gather y so that each ends with the full vector.  One exchange step, one
+kind of collective: all-gather over RCCL/xGMI (gloo in the CPU tests).
 
-`all_gather_into_tensor` needs equal-sized blocks, so each rank's block is
-padded to the largest block (`max_rows`); the kernel writes straight into the
-rank's slot of the padded buffer and `compact` copies the blocks back to back.
-When every block has the same number of rows the padded buffer IS y and the
-compaction disappears.
+xGMI is point-to-point (one link per GPU pair), so at N = 2..8 the gather costs
+as much as the kernel.  To overlap the two, every rank's rows are cut into
+`groups` consecutive row GROUPS (world x groups blocks in all, still nnz
+balanced); a step runs  kernel(g) -> async all-gather(g)  for g = 0..groups-1,
+so gather g travels while group g+1 is computed, and waits at the end.
+
+`all_gather_into_tensor` needs equal-sized pieces, so for each group the ranks'
+blocks are padded to the largest one; the kernel writes straight into the
+rank's slot of the group's padded buffer, the gather is in place, and the
+blocks are then copied back to back into y (skipped when nothing is padded).
 """
 from dataclasses import dataclass
 
@@ -20,56 +25,89 @@ import numpy as np
 @dataclass
 class ShardPlan:
     world: int
-    bounds: np.ndarray          # int64[world+1], rows of rank p = bounds[p]..bounds[p+1]
-    max_rows: int
+    groups: int
+    bounds: np.ndarray          # int64[world*groups+1]; block k = rank k // groups, group k % groups
+    max_rows: list              # per group: largest block of that group over the ranks
+
+    def block(self, rank, group):
+        k = rank * self.groups + group
+        return int(self.bounds[k]), int(self.bounds[k + 1])
+
+    def rows(self, rank):
+        """all rows of `rank` (its groups are consecutive)"""
+        return int(self.bounds[rank * self.groups]), int(self.bounds[(rank + 1) * self.groups])
+
+    @property
+    def M(self):
+        return int(self.bounds[-1])
 
     @property
     def equal_blocks(self):
-        return bool((np.diff(self.bounds) == self.max_rows).all())
+        """no padding anywhere and one group: the gather buffer IS y"""
+        d = np.diff(self.bounds)
+        return self.groups == 1 and bool((d == d[0]).all())
 
-    def rows(self, rank):
-        return int(self.bounds[rank]), int(self.bounds[rank + 1])
 
-
-def partition_by_nnz(irp, world):
+def partition_by_nnz(irp, parts):
     """Python twin of spmvHipPartitionRows (csrc/hip/abi.hip): boundary p is the row
-    whose starting offset is closest to p/world of the nnz."""
+    whose starting offset is closest to p/parts of the nnz."""
     irp = np.asarray(irp)
     M = irp.size - 1
     nnz = int(irp[-1]) - int(irp[0])
-    bounds = np.zeros(world + 1, dtype=np.int64)
-    for p in range(1, world):
-        target = int(irp[0]) + (nnz * p) // world
+    bounds = np.zeros(parts + 1, dtype=np.int64)
+    for p in range(1, parts):
+        target = int(irp[0]) + (nnz * p) // parts
         r = int(np.searchsorted(irp, target, side="left"))
         r = min(r, M)
         if r > 0 and target - int(irp[r - 1]) < int(irp[r]) - target:
             r -= 1
         bounds[p] = max(r, bounds[p - 1])
-    bounds[world] = M
+    bounds[parts] = M
     return bounds
 
 
-def make_plan(irp, world):
-    bounds = partition_by_nnz(irp, world)
-    return ShardPlan(world, bounds, int(np.diff(bounds).max()))
+def make_plan(irp, world, groups=1):
+    bounds = partition_by_nnz(irp, world * groups)
+    d = np.diff(bounds).reshape(world, groups)
+    return ShardPlan(world, groups, bounds, [int(d[:, g].max()) for g in range(groups)])
 
 
-def alloc_buffers(plan, rank, torch, device, dtype=None):
-    """(ypad, slot, y): padded gather buffer, this rank's slot in it, and the
-    contiguous result (aliases ypad when blocks are equal)."""
-    dtype = dtype or torch.float64
-    M = int(plan.bounds[-1])
-    ypad = torch.full((plan.world * plan.max_rows,), float("nan"), dtype=dtype, device=device)
-    slot = ypad[rank * plan.max_rows:(rank + 1) * plan.max_rows]
-    y = ypad[:M] if plan.equal_blocks else torch.full((M,), float("nan"), dtype=dtype, device=device)
-    return ypad, slot, y
+class GatherBuffers:
+    """Per group g: ypad[g] (world x max_rows[g]) and this rank's slot in it; y = the full vector."""
 
+    def __init__(self, plan, rank, torch, device, dtype=None):
+        dtype = dtype or torch.float64
+        self.plan, self.rank = plan, rank
+        self.ypad, self.slot = [], []
+        for g in range(plan.groups):
+            k = plan.max_rows[g]
+            buf = torch.full((plan.world * max(k, 1),), float("nan"), dtype=dtype, device=device)
+            self.ypad.append(buf)
+            self.slot.append(buf[rank * max(k, 1):(rank + 1) * max(k, 1)])
+        self.y = self.ypad[0][:plan.M] if plan.equal_blocks else \
+            torch.full((plan.M,), float("nan"), dtype=dtype, device=device)
 
-def gather_y(plan, dist, ypad, slot, y):
-    """All-gather the row blocks (in place) and compact them into y."""
-    dist.all_gather_into_tensor(ypad, slot)
-    if not plan.equal_blocks:
+    def compact(self, g):
+        """copy group g's gathered blocks to their rows of y"""
+        plan = self.plan
+        if plan.equal_blocks:
+            return
+        k = max(plan.max_rows[g], 1)
         for p in range(plan.world):
-            b0, b1 = plan.rows(p)
-            y[b0:b1].copy_(ypad[p * plan.max_rows:p * plan.max_rows + (b1 - b0)])
-    return y
+            b0, b1 = plan.block(p, g)
+            if b1 > b0:
+                self.y[b0:b1].copy_(self.ypad[g][p * k:p * k + (b1 - b0)])
+
+
+def step(plan, dist, bufs, compute_group):
+    """One sharded SpMV: for every group run `compute_group(g, slot_tensor)` (enqueues the kernels that
+    write this rank's rows of group g into the slot), then all-gather the group asynchronously; finally
+    wait for the gathers in order and compact.  Returns bufs.y."""
+    works = []
+    for g in range(plan.groups):
+        compute_group(g, bufs.slot[g])
+        works.append(dist.all_gather_into_tensor(bufs.ypad[g], bufs.slot[g], async_op=True))
+    for g, w in enumerate(works):
+        w.wait()
+        bufs.compact(g)
+    return bufs.y

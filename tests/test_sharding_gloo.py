@@ -22,7 +22,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, equal_rows, out_dir):
+def _worker(rank, world, port, equal_rows, groups, out_dir):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
@@ -36,30 +36,35 @@ def _worker(rank, world, port, equal_rows, out_dir):
         w = synth.Workload("p", 5003, 90000, "powerlaw", 3000, 9)
     lens = synth.row_lengths(w)
     irp = synth.prefix(lens)
-    plan = sharding.make_plan(irp, world)
-    r0, r1 = plan.rows(rank)
-    # this rank's shard, generated independently with its row offset (as on the GPUs)
-    ja, as_ = oracle.synth_fill(w.N, r0, irp[r0:r1 + 1], synth.SEED_STRUCT + w.cfg, synth.SEED_VAL + w.cfg, 0)
+    plan = sharding.make_plan(irp, world, groups)
     x = synth.make_x(w.N, w.cfg)
-    irp_local = (irp[r0:r1 + 1] - irp[r0]).astype(np.uint32)
-    y_local = oracle.csr_serial_dev(irp_local, ja, as_, x)
-    ypad, slot, y = sharding.alloc_buffers(plan, rank, torch, "cpu")
-    slot[: r1 - r0].copy_(torch.from_numpy(y_local))
-    sharding.gather_y(plan, dist, ypad, slot, y)
+    bufs = sharding.GatherBuffers(plan, rank, torch, "cpu")
+
+    def compute_group(g, slot):
+        # this rank's rows of group g, generated independently with their row offset (as on the GPUs)
+        b0, b1 = plan.block(rank, g)
+        ja, as_ = oracle.synth_fill(w.N, b0, irp[b0:b1 + 1], synth.SEED_STRUCT + w.cfg, synth.SEED_VAL + w.cfg, 0)
+        irp_local = (irp[b0:b1 + 1] - irp[b0]).astype(np.uint32)
+        slot[: b1 - b0].copy_(torch.from_numpy(oracle.csr_serial_dev(irp_local, ja, as_, x)))
+
+    for _ in range(2):                                   # two steps: buffers are re-used
+        y = sharding.step(plan, dist, bufs, compute_group)
     # reference: the whole matrix on one "device"
     ja_all, as_all = oracle.synth_fill(w.N, 0, irp, synth.SEED_STRUCT + w.cfg, synth.SEED_VAL + w.cfg, 0)
     y_ref = oracle.csr_serial_dev(irp.astype(np.uint32), ja_all, as_all, x)
     ok = np.array_equal(y.numpy(), y_ref) and not np.isnan(y.numpy()).any()
-    ok = ok and plan.equal_blocks == bool(equal_rows and w.N % world == 0)
+    ok = ok and plan.equal_blocks == bool(equal_rows and groups == 1 and w.N % world == 0)
+    r0, r1 = plan.rows(rank)
+    ok = ok and (r0, r1) == (plan.block(rank, 0)[0], plan.block(rank, groups - 1)[1])
     with open(os.path.join(out_dir, f"rank{rank}.txt"), "w") as f:
         f.write("ok" if ok else "mismatch")
     dist.barrier()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,equal_rows", [(2, False), (2, True), (3, False)])
-def test_sharded_spmv_gloo(tmp_path, world, equal_rows):
+@pytest.mark.parametrize("world,equal_rows,groups", [(2, False, 1), (2, True, 1), (3, False, 1), (2, False, 4), (3, True, 2)])
+def test_sharded_spmv_gloo(tmp_path, world, equal_rows, groups):
     port = _free_port()
-    mp.spawn(_worker, args=(world, port, equal_rows, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, port, equal_rows, groups, str(tmp_path)), nprocs=world, join=True)
     for r in range(world):
         assert (tmp_path / f"rank{r}.txt").read_text() == "ok"
