@@ -256,8 +256,28 @@ def cpu_baseline_and_check(api, synth, w, irp, x_host, y_gpu_fn, sample_nnz, ite
     return base, parity
 
 
+def emit(line):
+    """The ONE JSON line goes to the real stdout (saved before RCCL could write its banner there)."""
+    data = (json.dumps(line) + "\n").encode()
+    if _REAL_STDOUT is None:
+        sys.stdout.write(data.decode())
+        sys.stdout.flush()
+    else:
+        os.write(_REAL_STDOUT, data)
+
+
+_REAL_STDOUT = None
+
+
 def main():
+    global _REAL_STDOUT
     args = parse()
+    if args.gpus > 1 or args.force_dist:
+        # RCCL prints a version banner on fd 1 when the communicator comes up; the contract is ONE JSON
+        # line on stdout, so everything else of this process is sent to stderr
+        sys.stdout.flush()
+        _REAL_STDOUT = os.dup(1)
+        os.dup2(2, 1)
     import numpy as np
     import torch                      # BEFORE the HIP library: one HIP runtime per process (see api.py)
     import torch.distributed as dist
@@ -343,7 +363,7 @@ def main():
         for k in ("c3b", "c2"):
             if k in extra:
                 line["extra_" + k] = extra[k]
-        print(json.dumps(line), flush=True)
+        emit(line)
         api.spmvHipFinalize()
         return
 
@@ -426,7 +446,7 @@ def main():
             "exposed_gather_ms_per_step": wall_max / steps * 1e3 - kernel_ms_max,
             "parity": {"all_ranks_hold_identical_y": bool(same), "nan_left": float(chk_all[0][2])},
         }
-        print(json.dumps(line), flush=True)
+        emit(line)
     dist.barrier()
     for dm in dms:
         dm.free()

@@ -15,12 +15,15 @@ from spmv_openmp_cuda_amd import api, synth
 from conftest import Oracle
 
 scale = float(sys.argv[1]) if len(sys.argv) > 1 else 1.0
+band = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 oracle = Oracle()
 api.spmvHipInit(0)
 w = synth.WORKLOADS["c4"]
 if scale != 1.0:
     w = synth.scaled(w, scale)
     w.clip = 64
+if band:
+    w = synth.Workload(w.name + f"-band{band}", w.N, w.nnz, w.law, w.max_row, w.cfg, band, w.clip)
 lens = synth.row_lengths(w)
 irp = synth.prefix(lens)
 nnz, M, K = int(irp[-1]), w.N, int(lens.max())
@@ -30,7 +33,7 @@ dx = api.DeviceVector(M).up(x)
 dy = api.DeviceVector(M)
 # oracle on a 300 k-row window (twin-generated) as the checker
 r0, r1 = M // 3, M // 3 + 300_000
-ja, as_ = oracle.synth_fill(w.N, r0, irp[r0:r1 + 1], synth.SEED_STRUCT + w.cfg, synth.SEED_VAL + w.cfg, 0)
+ja, as_ = oracle.synth_fill(w.N, r0, irp[r0:r1 + 1], synth.SEED_STRUCT + w.cfg, synth.SEED_VAL + w.cfg, w.band)
 y_ref = oracle.csr_serial_dev((irp[r0:r1 + 1] - irp[r0]).astype(np.uint32), ja, as_, x)
 b_csr = synth.algorithmic_bytes_csr(nnz, M, M)
 b_ell = M * K * 12 + M * 8 + M * 8

@@ -648,7 +648,7 @@ int hipSpMVWarpsPerRowELLNTrasposed(spmat* dMat, double* dX, CONFIG cfg, double*
     while (G < WAVE && (uint64_t)G < d->K) G <<= 1;
     const unsigned bt = WG_THREADS;
     (void)cfg;
-    const uint64_t threads = d->M * (uint64_t)G;
+    const uint64_t threads = (d->M + ELL_GROUP_ROWS - 1) / ELL_GROUP_ROWS * (uint64_t)G;     // a group of G lanes owns 4 rows
     const dim3 grid = grid2d((threads + bt - 1) / bt, bt), block(bt);
     Launch L(grid, block);
     const bool rl = S.ellRowLens && d->RL;

@@ -399,24 +399,56 @@ __global__ __launch_bounds__(WG_THREADS) void ell_rowmajor_thread(
     y[row] = acc;
 }
 
-// Row-major + pitched, G lanes per row (G = 64 is the reference's
-// warp-per-row; smaller G packs 64/G short rows into one wavefront so lanes are
-// not idle when slots < 64).  Lanes stride the row, shuffle tree, group lane 0 stores.
+// Row-major + pitched, G lanes per row (G = 64 is the reference's warp-per-row; smaller G packs
+// 64/G short rows into one wavefront so lanes are not idle when slots < 64).  Lanes stride the row,
+// shuffle tree, group lane 0 stores.  Every group owns ELL_GROUP_ROWS consecutive rows and issues
+// the loads of all of them before the first gather: one row per wavefront is latency-bound
+// (load -> gather -> 6 shuffles -> store per row), four rows in flight are not.
+constexpr int ELL_GROUP_ROWS = 4;
+
 template <bool USE_RL, int G>
 __global__ __launch_bounds__(WG_THREADS) void ell_rowmajor_group(
     uint32_t rows, uint32_t slots, size_t pitch, const uint32_t* __restrict__ JA,
     const double* __restrict__ AS, const uint32_t* __restrict__ RL,
     const double* __restrict__ x, double* __restrict__ y) {
     const uint64_t gid = linear_block() * blockDim.x + threadIdx.x;
-    const uint64_t row = gid / G;
+    const uint64_t row0 = (gid / G) * ELL_GROUP_ROWS;
     const uint32_t l = (uint32_t)(gid % G);
-    const bool live = row < rows;
-    const uint32_t n = live ? (USE_RL ? RL[row] : slots) : 0u;
-    const size_t p = (size_t)row * pitch;
-    double acc = 0;
-    for (uint32_t c = l; c < n; c += G) acc += stream_load(AS + p + c) * x[stream_load(JA + p + c)];
-    acc = group_sum<G>(acc);
-    if (live && l == 0) y[row] = acc;
+    double acc[ELL_GROUP_ROWS];
+    uint32_t n[ELL_GROUP_ROWS];
+#pragma unroll
+    for (int r = 0; r < ELL_GROUP_ROWS; ++r) {
+        const uint64_t row = row0 + r;
+        n[r] = row < rows ? (USE_RL ? RL[row] : slots) : 0u;
+        acc[r] = 0;
+    }
+    if (slots <= (uint32_t)G) {
+        // one access per row: all loads first, then all gathers
+        uint32_t c[ELL_GROUP_ROWS];
+        double a[ELL_GROUP_ROWS];
+#pragma unroll
+        for (int r = 0; r < ELL_GROUP_ROWS; ++r) {
+            const size_t p = (size_t)(row0 + r) * pitch + l;
+            const bool in = l < n[r];
+            c[r] = in ? stream_load(JA + p) : 0u;
+            a[r] = in ? stream_load(AS + p) : 0.0;
+        }
+#pragma unroll
+        for (int r = 0; r < ELL_GROUP_ROWS; ++r) acc[r] = a[r] * x[c[r]];
+    } else {
+#pragma unroll
+        for (int r = 0; r < ELL_GROUP_ROWS; ++r) {
+            const size_t p = (size_t)(row0 + r) * pitch;
+            for (uint32_t k = l; k < n[r]; k += G) acc[r] += stream_load(AS + p + k) * x[stream_load(JA + p + k)];
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < ELL_GROUP_ROWS; ++r) acc[r] = group_sum<G>(acc[r]);
+    if (l == 0) {
+#pragma unroll
+        for (int r = 0; r < ELL_GROUP_ROWS; ++r)
+            if (row0 + r < rows) y[row0 + r] = acc[r];
+    }
 }
 
 }  // namespace spmvhip

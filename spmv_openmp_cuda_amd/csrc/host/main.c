@@ -10,7 +10,8 @@
  * Environment: SPMV_DEVICE (default 0), SPMV_BLOCK_X (threads per workgroup,
  * multiple of 64; default = library choice), SPMV_VARIANT (kernel variant of
  * the selected launcher, see spmvHip.h), SPMV_ELL_ROWLENS=0 to walk the ELL
- * padding like the reference kernels.
+ * padding like the reference kernels, SPMV_NGPU=n (CSR row modes only): shard
+ * the rows over n devices and all-gather y with RCCL (spmvHipShardCSR).
  */
 #include <math.h>
 #include <stdio.h>
@@ -75,6 +76,25 @@ int main(int argc, char** argv) {
         if (vectSize != mat->N) { ERRPRINT("vector not compatible with sparse matrix\n"); goto _free; }
     }
     if (!(outV = malloc((mat->M ? mat->M : 1) * sizeof *outV))) { ERRPRINT("outV malloc errd\n"); goto _free; }
+
+    /* ---- multi-device path (new; the reference is single-GPU) */
+    const long nGpu = envLong("SPMV_NGPU", 1);
+    if (nGpu > 1 || getenv("SPMV_NGPU")) {
+        if (cmode != _CUDA_CSR_ROWS && cmode != _CUDA_CSR_ROWS_WARP) { ERRPRINT("SPMV_NGPU needs CUDA_CSR_ROWS or CUDA_CSR_ROWS_WARP\n"); goto _free; }
+        void* shards = NULL;
+        double kSec = 0, gSec = 0;
+        if (spmvHipShardCSR(mat, (int)nGpu, &shards)) goto _free;
+        int rc = spmvHipSpMVSharded(shards, vector, cmode == _CUDA_CSR_ROWS_WARP, outV, &kSec, &gSec);
+        spmvHipShardFree(shards);
+        if (rc) { ERRPRINT("sharded SpMV failed\n"); goto _free; }
+        Elapsed = ElapsedInternal = (kSec + gSec) * 1e3;
+        if (writeDoubleVector(OUTVECTORDUMPRAW, outV, mat->M) || writeDoubleVectorAsStr(OUTVECTORDUMP, outV, mat->M))
+            ERRPRINT("outV dump err\n");
+        printf("nGPU: %ld\tkernelSeconds:%le gatherSeconds:%le GFLOPS:%lf\n", nGpu, kSec, gSec, 2.0 * mat->NZ / (kSec + gSec) * 1e-9);
+        printf("cmode:%d\telapsed:\t %le elapsedInternal %le\n", cmode, Elapsed, ElapsedInternal);
+        out = EXIT_SUCCESS;
+        goto _free;
+    }
 
     /* ---- host -> device */
     if (spmvHipVecAlloc(&dVect, mat->N) || spmvHipVecAlloc(&dOutV, mat->M)) goto _free;

@@ -250,3 +250,63 @@ def test_device_csr_to_ell(api, oracle, name):
         dell.free()
     api.lib.spmvHipSetEllRowLens(1)
     dcsr.free()
+
+
+def test_64bit_row_pointers_small(api, oracle):
+    """The uint64_t row-pointer instantiations of every CSR kernel, on a small adopted matrix."""
+    import ctypes as C
+    from spmv_openmp_cuda_amd import synth
+    M, N, IRP, JA, AS = CASES["irregular"]
+    x = _x(np.random.default_rng(3), N)
+    y_ref = oracle.csr_serial(IRP, JA, AS, x)
+    d_irp = api.DeviceBuffer(IRP.nbytes).up(IRP.astype(np.uint64))
+    d_ja = api.DeviceBuffer(4 * JA.size).up(JA.astype(np.uint32))
+    d_as = api.DeviceBuffer(8 * AS.size).up(AS)
+    dm = api.DeviceMatrix()
+    assert api.lib.spmvHipAdoptCSR(C.byref(dm.handle), M, N, JA.size, d_irp.ptr, 8, d_ja.ptr, d_as.ptr, None) == 0
+    dm.keep = [d_irp, d_ja, d_as]
+    for launcher, variants, exact in (("hipSpMVRowsCSR", (0, 1, 2), True), ("hipSpMVWarpPerRowCSR", (0, 1, 2), False),
+                                      ("hipSpMVTilesCSR", (-1,), False)):
+        for v in variants:
+            if v >= 0:
+                api.set_variant(launcher, v)
+            y = _run(api, launcher, dm, x, M)
+            assert not np.isnan(y).any() and np.max(np.abs(y - y_ref)) <= GATE
+            if exact:
+                assert np.array_equal(y, y_ref)
+    api.set_variant("hipSpMVRowsCSR", 2)
+    api.set_variant("hipSpMVWarpPerRowCSR", 2)
+    dm.free()
+
+
+def test_more_than_4g_nnz(api, oracle):
+    """Maximum-size edge: nnz >= 2^32 (4.4 G entries, ~53 GB of HBM) forces 64-bit row pointers end to end.
+    Rows at the head, across the 2^32-entry boundary and at the tail must match the oracle; the
+    two-phase kernel (32-bit positions) must refuse cleanly."""
+    import ctypes as C
+    from spmv_openmp_cuda_amd import synth
+    w = synth.Workload("huge-uniform-100M-44", 100_000_000, 4_400_000_000, "uniform", cfg=7)
+    lens = synth.row_lengths(w)
+    irp = synth.prefix(lens)
+    assert int(irp[-1]) >= 1 << 32
+    dm = synth.device_csr(w, irp, 0, w.N)
+    assert dm.irp_bytes == 8
+    x = synth.make_x(w.N, w.cfg)
+    dx = api.DeviceVector(w.N).up(x)
+    dy = api.DeviceVector(w.N)
+    cross = int(np.searchsorted(irp, 1 << 32)) - 50_000
+    ranges = [(0, 100_000), (cross, cross + 100_000), (w.N - 100_000, w.N)]
+    for launcher, exact in (("hipSpMVWarpPerRowCSR", False), ("hipSpMVRowsCSR", True)):
+        dy.poison()
+        api.spmv(launcher, dm, dx, dy)
+        y = dy.down()
+        assert not np.isnan(y).any()
+        for r0, r1 in ranges:
+            ja, as_ = oracle.synth_fill(w.N, r0, irp[r0:r1 + 1], synth.SEED_STRUCT + w.cfg, synth.SEED_VAL + w.cfg, 0)
+            yr = oracle.csr_serial_dev((irp[r0:r1 + 1] - irp[r0]).astype(np.uint32), ja, as_, x)
+            assert np.max(np.abs(y[r0:r1] - yr)) <= GATE
+            if exact:
+                assert np.array_equal(y[r0:r1], yr)
+    with pytest.raises(api.SpmvHipError):
+        api.spmv("hipSpMVTilesCSR", dm, dx, dy)
+    dm.free()

@@ -37,6 +37,16 @@ def test_cli_against_reference_cli_output(name, mode):
     assert np.allclose(txt, y, rtol=1e-6, atol=0)
 
 
+def test_cli_sharded_env():
+    """SPMV_NGPU=1 drives the spmvHipShardCSR path from the CLI."""
+    g = load_golden("rand300")
+    r = subprocess.run([CLI, os.path.join(GOLD, "rand300.mtx"), os.path.join(GOLD, "x_rand300.bin"), "CUDA_CSR_ROWS"],
+                       capture_output=True, text=True, timeout=120, env=dict(os.environ, SPMV_NGPU="1"))
+    assert r.returncode == 0 and "nGPU: 1" in r.stdout, r.stdout + r.stderr
+    y = np.fromfile("/tmp/outVectorDumpRaw")
+    assert np.max(np.abs(y - g["y_csr"])) <= 1e-19
+
+
 def test_cli_rejects_bad_usage():
     mtx = os.path.join(GOLD, "cage4like.mtx")
     x = os.path.join(GOLD, "x_cage4like.bin")
