@@ -98,8 +98,15 @@ static const SPMV_HIP_INTERF SpmvCUDA_ELLFuncs[] = {
 SPMV sgemvSerial;           /* SpMV_CSR_OMP.c:229-250 */
 SPMV spmvRowsBasicCSR;      /* SpMV_CSR_OMP.c:34-63   */
 SPMV spmvRowsBasicELL;      /* SpMV_ELL_OMP.c:33-67   */
-static const SPMV_INTERF SpmvCSRFuncs[] = { &sgemvSerial, &spmvRowsBasicCSR };
-static const SPMV_INTERF SpmvELLFuncs[] = { &spmvRowsBasicELL };
+SPMV spmvRowsBlocksCSR;     /* SpMV_CSR_OMP.c:65-99   -- CPU comparators, SURVEY 8f-1 */
+SPMV spmvTilesCSR;          /* SpMV_CSR_OMP.c:101-162 */
+SPMV spmvTilesAllocdCSR;    /* SpMV_CSR_OMP.c:165-226 */
+SPMV spmvRowsBlocksELL;     /* SpMV_ELL_OMP.c:69-108  */
+SPMV spmvTilesELL;          /* SpMV_ELL_OMP.c:110-174 */
+/* same order as the reference's tables (SpMV.h:146-159) */
+static const SPMV_INTERF SpmvCSRFuncs[] = { &sgemvSerial, &spmvRowsBasicCSR, &spmvRowsBlocksCSR, &spmvTilesCSR,
+                                            &spmvTilesAllocdCSR };
+static const SPMV_INTERF SpmvELLFuncs[] = { &spmvRowsBasicELL, &spmvRowsBlocksELL, &spmvTilesELL };
 #endif
 
 #ifdef __cplusplus

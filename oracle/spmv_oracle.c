@@ -11,6 +11,8 @@
  *   oracleVectorsDiffRef                         follows src/commons/utils.c:362-393
  *                                                (incl. its "NaN passes" behaviour)
  *
+ * (the reference's other five OpenMP variants are restated in spmv_oracle_tiles.c)
+ *
  * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
  * build, link, load or call this file.  Nothing under spmv_openmp_cuda_amd/
  * does; the GPU library has no CPU fallback.

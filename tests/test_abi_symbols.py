@@ -47,8 +47,9 @@ def test_host_library_exports_its_headers():
 
 def test_oracle_exports_the_cpu_side_of_the_dispatch_surface():
     lib = C.CDLL(os.path.join(ROOT, "oracle", "liboracle.so"))
-    for n in ("sgemvSerial", "spmvRowsBasicCSR", "spmvRowsBasicELL", "chunksNOOP", "chunksFair",
-              "chunksFairFolded", "ompGetRuntimeSchedule"):
+    for n in ("sgemvSerial", "spmvRowsBasicCSR", "spmvRowsBasicELL", "spmvRowsBlocksCSR", "spmvTilesCSR",
+              "spmvTilesAllocdCSR", "spmvRowsBlocksELL", "spmvTilesELL", "colsOffsetsPartitioningUnifRanges",
+              "colsPartitioningUnifRanges", "chunksNOOP", "chunksFair", "chunksFairFolded", "ompGetRuntimeSchedule"):
         assert hasattr(lib, n)
 
 

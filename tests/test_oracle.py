@@ -55,10 +55,14 @@ def _cfg(cls, lib_fn_ptr, threads):
     return c
 
 
+ALL_CSR = ("sgemvSerial", "spmvRowsBasicCSR", "spmvRowsBlocksCSR", "spmvTilesCSR", "spmvTilesAllocdCSR")
+ALL_ELL = ("spmvRowsBasicELL", "spmvRowsBlocksELL", "spmvTilesELL")
+
+
 @pytest.fixture(scope="module")
 def olib(oracle):
     lib = oracle.lib
-    for fn in ("sgemvSerial", "spmvRowsBasicCSR", "spmvRowsBasicELL"):
+    for fn in ALL_CSR + ALL_ELL:
         getattr(lib, fn).argtypes = [C.POINTER(spmat), C.c_void_p, C.POINTER(CONFIG), C.c_void_p]
     return lib
 
@@ -67,9 +71,10 @@ def _fn_addr(lib, name):
     return C.cast(getattr(lib, name), C.c_void_p).value
 
 
-def _run_oracle(olib, fn, m, x):
+def _run_oracle(olib, fn, m, x, grid=(8, 8)):
     y = np.full(m.M, np.nan)
     cfg = _cfg(CONFIG, _fn_addr(olib, "chunksNOOP"), 1)
+    cfg.gridRows, cfg.gridCols = grid
     assert getattr(olib, fn)(C.byref(m), x.ctypes.data_as(C.c_void_p), C.byref(cfg), y.ctypes.data_as(C.c_void_p)) == 0
     return y
 
@@ -108,6 +113,20 @@ def test_omp_csr_and_ell_vs_golden(olib, name):
             assert np.array_equal(y, g["y_ell"])
 
 
+@pytest.mark.parametrize("name", NAMES)
+def test_all_cpu_variants_vs_golden(olib, name):
+    g = load_golden(name)
+    m = _struct(spmat, g["M"], g["N"], g["NZ"], g["IRP"], g["JA"], g["AS"], g["RL"])
+    e = _struct(spmat, g["M"], g["N"], g["NZ"], None, g["ELL_JA"], g["ELL_AS"], g["RL"], g["K"])
+    for grid in ((8, 8), (2, 3)):
+        for fn in ALL_CSR:
+            y = _run_oracle(olib, fn, m, g["x"], grid)
+            assert tight_error(g["IRP"], g["JA"], g["AS"], g["x"], g["y_csr"], y) <= 1e-15, (fn, grid)
+        for fn in ALL_ELL:
+            y = _run_oracle(olib, fn, e, g["x"], grid)
+            assert tight_error(g["IRP"], g["JA"], g["AS"], g["x"], g["y_ell"], y) <= 1e-15, (fn, grid)
+
+
 def test_reference_gate_semantics(oracle):
     """oracleVectorsDiffRef restates utils.c:362-393 including its NaN blind spot."""
     a = np.array([1.0, 2.0, 3.0])
@@ -125,7 +144,7 @@ def test_restatement_equals_compiled_reference(olib):
     ref = C.CDLL(REF_LIB)
     assert ref.refSizeofSpmat() == C.sizeof(ref_spmat) and ref.refSizeofConfig() == C.sizeof(ref_CONFIG)
     ref.refChunksNOOP.restype = C.c_void_p
-    for fn in ("sgemvSerial", "spmvRowsBasicCSR", "spmvRowsBasicELL"):
+    for fn in ALL_CSR + ALL_ELL:
         getattr(ref, fn).argtypes = [C.POINTER(ref_spmat), C.c_void_p, C.POINTER(ref_CONFIG), C.c_void_p]
     rng = np.random.default_rng(99)
     for trial in range(6):
@@ -139,11 +158,23 @@ def test_restatement_equals_compiled_reference(olib):
         mr = _struct(ref_spmat, M, N, JA.size, IRP, JA, AS, RL)
         mo = _struct(spmat, M, N, JA.size, IRP, JA, AS, RL)
         cr = _cfg(ref_CONFIG, ref.refChunksNOOP(), ref.refMaxThreads())
-        for fn in ("sgemvSerial", "spmvRowsBasicCSR"):
-            yr = np.full(M, np.nan)
-            assert getattr(ref, fn)(C.byref(mr), x.ctypes.data_as(C.c_void_p), C.byref(cr), yr.ctypes.data_as(C.c_void_p)) == 0
-            yo = _run_oracle(olib, fn, mo, x)
-            assert np.array_equal(yr, yo), fn
+        grids = [(8, 8), (3, 5), (1, 1), (40, 2)] if trial < 3 else [(8, 8)]
+        for grid in grids:
+            cr.gridRows, cr.gridCols = grid
+            # the reference's spmvTilesAllocdCSR double-frees when a column partition holds no entry
+            # (realloc(p, 0) == NULL is treated as an error, sparseUtils.c:118-127): only compare where it survives
+            gc = grid[1]
+            cb, rem = N // gc, N % gc
+            starts = [g * cb + min(g, rem) for g in range(gc + 1)]
+            per_part = np.histogram(JA.astype(np.int64), bins=starts)[0] if JA.size else np.zeros(gc)
+            for fn in ALL_CSR:
+                yo = _run_oracle(olib, fn, mo, x, grid)
+                if fn == "spmvTilesAllocdCSR" and (per_part == 0).any():
+                    assert np.array_equal(yo, _run_oracle(olib, "spmvTilesCSR", mo, x, grid))   # same tiles, same sums
+                    continue
+                yr = np.full(M, np.nan)
+                assert getattr(ref, fn)(C.byref(mr), x.ctypes.data_as(C.c_void_p), C.byref(cr), yr.ctypes.data_as(C.c_void_p)) == 0
+                assert np.array_equal(yr, yo), (fn, grid)
         # ELL through each side's own layout
         K = int(lens.max()) if M else 0
         EJ = np.zeros((M, max(K, 1)), dtype=np.uint64)[:, :K].copy()
@@ -153,9 +184,12 @@ def test_restatement_equals_compiled_reference(olib):
             EJ[r, :l], EA[r, :l] = JA[b:b + l], AS[b:b + l]
         er = _struct(ref_spmat, M, N, JA.size, None, EJ, EA, RL, K)
         eo = _struct(spmat, M, N, JA.size, None, EJ, EA, RL, K)
-        yr = np.full(M, np.nan)
-        assert ref.spmvRowsBasicELL(C.byref(er), x.ctypes.data_as(C.c_void_p), C.byref(cr), yr.ctypes.data_as(C.c_void_p)) == 0
-        assert np.array_equal(yr, _run_oracle(olib, "spmvRowsBasicELL", eo, x))
+        for grid in grids:
+            cr.gridRows, cr.gridCols = grid
+            for fn in ALL_ELL:
+                yr = np.full(M, np.nan)
+                assert getattr(ref, fn)(C.byref(er), x.ctypes.data_as(C.c_void_p), C.byref(cr), yr.ctypes.data_as(C.c_void_p)) == 0
+                assert np.array_equal(yr, _run_oracle(olib, fn, eo, x, grid)), (fn, grid)
 
 
 def test_synth_twin_properties(oracle):
