@@ -310,3 +310,40 @@ def test_more_than_4g_nnz(api, oracle):
     with pytest.raises(api.SpmvHipError):
         api.spmv("hipSpMVTilesCSR", dm, dx, dy)
     dm.free()
+
+
+def test_upload_validation_and_handle_lifecycle(api, capfd):
+    """Bad inputs are refused with EXIT_FAILURE (never a crash), freed handles are rejected."""
+    import ctypes as C
+    M, N, IRP, JA, AS = CASES["cage4-shaped"]
+    bad_col = JA.copy()
+    bad_col[3] = N + 5                                    # column outside the matrix
+    with pytest.raises(api.SpmvHipError):
+        api.spMatCpyCSR(api.HostCSR(M, N, IRP, bad_col, AS))
+    bad_irp = IRP.copy()
+    bad_irp[-1] += 1                                      # IRP[M] != NZ
+    h = api.HostCSR(M, N, IRP, JA, AS)
+    h.IRP[-1] += 1
+    with pytest.raises(api.SpmvHipError):
+        api.spMatCpyCSR(h)
+    h.IRP[-1] -= 1
+    dmat = api.spMatCpyCSR(h)
+    dx, dy = api.DeviceVector(N), api.DeviceVector(M)
+    api.spmv("hipSpMVRowsCSR", dmat, dx.up(np.ones(N)), dy)
+    assert api.lib.hipFreeSpmat(C.byref(dmat.handle)) == 0
+    assert api.lib.hipFreeSpmat(C.byref(dmat.handle)) == 0          # idempotent
+    with pytest.raises(api.SpmvHipError):
+        api.spmv("hipSpMVRowsCSR", dmat, dx, dy)                    # freed handle
+    # a block size that is not a multiple of the 64-lane wavefront falls back to the default (with a message)
+    dmat = api.spMatCpyCSR(h)
+    cfg = api.CONFIG()
+    cfg.blockSize.x = 100
+    api.set_variant("hipSpMVRowsCSR", 0)
+    api.spmv("hipSpMVRowsCSR", dmat, dx, dy, cfg)
+    assert api.last_launch()[1][0] == 256
+    cfg.blockSize.x = 128
+    api.spmv("hipSpMVRowsCSR", dmat, dx, dy, cfg)
+    assert api.last_launch()[1][0] == 128
+    api.set_variant("hipSpMVRowsCSR", 2)
+    dmat.free()
+    assert "not a multiple of the 64-lane wavefront" in capfd.readouterr().err

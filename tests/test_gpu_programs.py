@@ -61,7 +61,7 @@ def test_harness_all_implementations_pass(name):
                        capture_output=True, text=True, timeout=300, env=dict(os.environ, OMP_NUM_THREADS="4"))
     assert r.returncode == 0, r.stdout + r.stderr
     out = r.stdout
-    assert out.count("cudaBlockSize:") == 6 and out.count("threadNum:") == 3     # 3 CSR + 3 ELL launchers, 3 OpenMP
+    assert out.count("cudaBlockSize:") == 6 and out.count("threadNum:") == 8     # 3 CSR + 3 ELL launchers; 5 + 3 OpenMP variants like the reference
     assert "AVG_TIMES_ITERATION:25" in out and "MAX_ROW_NZ" in out and "omp sched gather:" in out
 
 
