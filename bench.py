@@ -84,17 +84,22 @@ def kernel_ms(api, ev_pairs):
     return out
 
 
-AUTO_CANDIDATES = ("hipSpMVWarpPerRowCSR", "hipSpMVTilesCSR")
+KERNEL_OF = {"hipSpMVTilesCSR": "pb_expand_kernel + pb_reduce_kernel", "hipSpMVWarpPerRowCSR": "csr_stream2_kernel",
+             "hipSpMVRowsCSR": "csr_stream2_kernel", "hipSpMVRowsSELL": "sell_spmv_kernel"}
+AUTO_CANDIDATES = ("hipSpMVWarpPerRowCSR", "hipSpMVTilesCSR", "hipSpMVRowsSELL")
 
 
-def pick_launcher(api, torch, dm, x_ptr, y_ptr, requested):
+THREAD_PER_ROW = ("hipSpMVRowsCSR", "hipSpMVRowsSELL")      # both add a row's products in ascending j with one lane
+
+
+def pick_launcher(api, torch, dm, x_ptr, y_ptr, requested, candidates=None):
     """'auto' -> run each candidate 3x (first call of the tiles launcher also builds its
     slice-major format) and keep the faster; returns (name, {name: ms})."""
     if requested != "auto":
         return requested, {}
     cfg = api.CONFIG()
     times = {}
-    for name in AUTO_CANDIDATES:
+    for name in (candidates or AUTO_CANDIDATES):
         fn = api.SPMV_LAUNCHERS[name]
         if fn(C.byref(dm.handle), x_ptr, cfg, y_ptr):
             continue                                  # e.g. tiles unsupported for this shape: skip
@@ -118,7 +123,7 @@ def pmc_traffic(workload_name, launcher):
         return None
 
 
-def measure_single(api, synth, torch, w, launcher, steps, warmup):
+def measure_single(api, synth, torch, w, launcher, steps, warmup, candidates=None):
     """1-GPU measurement of workload `w`; returns (dict, context for checks)."""
     import numpy as np
     lens = synth.row_lengths(w)
@@ -128,7 +133,7 @@ def measure_single(api, synth, torch, w, launcher, steps, warmup):
     x_host = synth.make_x(w.N, w.cfg)
     x = torch.from_numpy(x_host).cuda()
     y = torch.full((w.N,), float("nan"), dtype=torch.float64, device="cuda")
-    launcher, tried = pick_launcher(api, torch, dm, x.data_ptr(), y.data_ptr(), launcher)
+    launcher, tried = pick_launcher(api, torch, dm, x.data_ptr(), y.data_ptr(), launcher, candidates)
     y.fill_(float("nan"))
     fn = api.SPMV_LAUNCHERS[launcher]
     cfg = api.CONFIG()
@@ -156,7 +161,8 @@ def measure_single(api, synth, torch, w, launcher, steps, warmup):
     k_avg = sum(kms) / len(kms) * 1e-3
     res = {
         "workload": info, "launcher": launcher, "auto_candidates_ms": tried,
-        "extra_device_bytes": int(api.lib.spmvHipTilesBytes(C.byref(dm.handle))) if launcher == "hipSpMVTilesCSR" else 0,
+        "extra_device_bytes": int(api.lib.spmvHipTilesBytes(C.byref(dm.handle))) if launcher == "hipSpMVTilesCSR" else
+                              int(api.lib.spmvHipSellBytes(C.byref(dm.handle))) if launcher == "hipSpMVRowsSELL" else 0,
         "ms_per_step": wall / steps * 1e3, "kernel_ms_avg": k_avg * 1e3, "kernel_ms_min": min(kms),
         "gflops": 2.0 * nnz / (wall / steps) * 1e-9,
         "hbm_gbps": bytes_alg / k_avg * 1e-9, "hbm_frac": bytes_alg / k_avg / HBM_PEAK,
@@ -332,8 +338,9 @@ def main():
                 we = synth.WORKLOADS[key]
                 if args.scale != 1.0:
                     we = synth.scaled(we, args.scale)
-                launcher = "hipSpMVRowsCSR" if key.startswith("c2") else args.launcher
-                r, c = measure_single(api, synth, torch, we, launcher, steps, warmup)
+                # config 2 is quoted on a thread-per-row kernel: pick among the one-lane-per-row launchers only
+                cands = THREAD_PER_ROW if key.startswith("c2") else None
+                r, c = measure_single(api, synth, torch, we, args.launcher, steps, warmup, cands)
                 launcher = r["launcher"]
                 c["dm"].free()
                 del c
@@ -351,7 +358,7 @@ def main():
             "hbm_gbps": res["hbm_gbps"], "hbm_roofline_frac": res["hbm_frac"],
             "roofline": {"bound": "hbm", "achieved": res["hbm_gbps"], "peak": HBM_PEAK * 1e-9, "unit": "GB/s",
                          "frac": res["hbm_frac"], "traffic": pmc_traffic(res["workload"]["workload"], res["launcher"]),
-                         "kernel": "pb_expand_kernel + pb_reduce_kernel" if res["launcher"] == "hipSpMVTilesCSR" else "csr_stream2_kernel",
+                         "kernel": KERNEL_OF.get(res["launcher"], res["launcher"]),
                          "algorithmic_bytes_per_launch": res["algorithmic_bytes"],
                          "kernel_ms_avg": res["kernel_ms_avg"]},
         }
@@ -440,7 +447,7 @@ def main():
             "hbm_roofline_frac": bytes_alg_total / (wall_max / steps) / (HBM_PEAK * world),
             "roofline": {"bound": "hbm", "achieved": bytes_alg_local / k_avg * 1e-9, "peak": HBM_PEAK * 1e-9,
                          "unit": "GB/s", "frac": bytes_alg_local / k_avg / HBM_PEAK, "traffic": None,
-                         "kernel": "pb_expand_kernel + pb_reduce_kernel" if launcher == "hipSpMVTilesCSR" else "csr_stream2_kernel",
+                         "kernel": KERNEL_OF.get(launcher, launcher),
                          "algorithmic_bytes_per_launch": bytes_alg_local,
                          "kernel_ms_avg": kernel_ms_max, "note": "per-rank kernels (all row groups), slowest rank"},
             "exposed_gather_ms_per_step": wall_max / steps * 1e3 - kernel_ms_max,

@@ -35,6 +35,8 @@ extern "C" {
 #define CUDA_ELL_ROWS_WARP_NT   "CUDA_ELL_ROWS_WARP_NN_TRANSPOSED"
 #define CUDA_CSR_TILES          "CUDA_CSR_TILES"                   /* new: column-sliced two-phase kernel */
 #define HIP_CSR_TILES           "HIP_CSR_TILES"
+#define CUDA_SELL_ROWS          "CUDA_SELL_ROWS"                   /* new: SELL-C-sigma, one lane per row */
+#define HIP_SELL_ROWS           "HIP_SELL_ROWS"
 #define HIP_CSR_ROWS            "HIP_CSR_ROWS"
 #define HIP_CSR_ROWS_WARP       "HIP_CSR_ROWS_WARP"
 #define HIP_ELL_ROWS            "HIP_ELL_ROWS"
@@ -57,6 +59,7 @@ typedef enum {              /* same order and values as SpMV.h:42-59 */
     _CUDA_ELL_ROWS_WARP_NT,
     _CUDA_ELL_ROWS_NT,      /* appended: row-major thread-per-row ELL */
     _CUDA_CSR_TILES,        /* appended: column-sliced two-phase CSR */
+    _CUDA_SELL_ROWS,        /* appended: SELL-C-sigma built from the CSR upload */
     _COMPUTE_MODE_INVALID = -1
 } COMPUTE_MODE;
 
@@ -64,7 +67,8 @@ typedef enum {              /* same order and values as SpMV.h:42-59 */
 COMPUTE_MODE spmvModeFromString(const char* name);
 static inline int spmvModeIsGpu(COMPUTE_MODE m) { return m >= _CUDA_CSR_ROWS; }
 static inline int spmvModeIsCsr(COMPUTE_MODE m) {
-    return m <= _CSR_TILES_ALLOCD || m == _CUDA_CSR_ROWS || m == _CUDA_CSR_ROWS_WARP || m == _CUDA_CSR_TILES;
+    return m <= _CSR_TILES_ALLOCD || m == _CUDA_CSR_ROWS || m == _CUDA_CSR_ROWS_WARP || m == _CUDA_CSR_TILES ||
+           m == _CUDA_SELL_ROWS;
 }
 
 /* y = A x: (matrix, x, run configuration, y) -> EXIT_SUCCESS / EXIT_FAILURE */
@@ -76,6 +80,7 @@ static const SPMV_HIP_INTERF SpmvCUDA_CSRFuncs[] = {
     &hipSpMVRowsCSR,
     &hipSpMVWarpPerRowCSR,
     &hipSpMVTilesCSR,           /* appended: no counterpart in the reference's GPU table */
+    &hipSpMVRowsSELL,           /* appended: SELL-C-sigma copy of the CSR matrix */
 };
 #define SpmvCUDA_CSRFuncs_WarpPerRowIdx     1
 #define SpmvCUDA_CSRFuncs_TilesIdx          2

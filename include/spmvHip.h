@@ -115,6 +115,16 @@ SPMV_HIP hipSpMVTilesCSR;
 int    spmvHipBuildTiles(spmat* dMat);
 size_t spmvHipTilesBytes(spmat* dMat);
 
+/* SELL-C-sigma (C = 64 rows per slice = one wavefront, rows sorted by length inside 16 Ki-row
+ * windows, column-major inside a slice) built on the device from an uploaded CSR handle at the
+ * first call: the ELL-family kernel for matrices whose longest row makes plain ELL impossible
+ * (the reference's loader refuses them, src/lib/parser.c:223-232).  One lane per
+ * row, ascending-j order: bit-identical to the serial oracle for rows up to 256 entries;
+ * longer rows are summed by a whole workgroup (shuffle tree). */
+SPMV_HIP hipSpMVRowsSELL;
+int    spmvHipBuildSell(spmat* dMat);
+size_t spmvHipSellBytes(spmat* dMat);
+
 /* Enqueue-only form of the two CSR launchers on an explicit stream (no timing
  * bracket, no synchronisation): warpPerRow = 0 -> hipSpMVRowsCSR semantics,
  * != 0 -> hipSpMVWarpPerRowCSR.  The current device must be the matrix'. */

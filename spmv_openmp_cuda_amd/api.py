@@ -53,6 +53,8 @@ _sigs = {
     "spmvHipCsrToEll": ([C.POINTER(spmat), _i, C.POINTER(spmat)], _i),
     "spmvHipAdoptCSR": ([C.POINTER(spmat), C.c_ulong, C.c_ulong, C.c_ulong, _vp, _i, _vp, _vp, _vp], _i),
     "hipSpMVRowsCSR": (_SPMV_ARGS, _i), "hipSpMVWarpPerRowCSR": (_SPMV_ARGS, _i),
+    "hipSpMVRowsSELL": (_SPMV_ARGS, _i), "spmvHipBuildSell": ([C.POINTER(spmat)], _i),
+    "spmvHipSellBytes": ([C.POINTER(spmat)], _sz),
     "hipSpMVTilesCSR": (_SPMV_ARGS, _i), "spmvHipBuildTiles": ([C.POINTER(spmat)], _i),
     "spmvHipTilesBytes": ([C.POINTER(spmat)], _sz),
     "spmvHipEnqueueCSR": ([C.POINTER(spmat), _i, _vp, _vp, _vp], _i),
@@ -99,6 +101,7 @@ SPMV_LAUNCHERS = {
     "hipSpMVRowsCSR": lib.hipSpMVRowsCSR,
     "hipSpMVWarpPerRowCSR": lib.hipSpMVWarpPerRowCSR,
     "hipSpMVTilesCSR": lib.hipSpMVTilesCSR,
+    "hipSpMVRowsSELL": lib.hipSpMVRowsSELL,
     "hipSpMVRowsELL": lib.hipSpMVRowsELL,
     "hipSpMVRowsELLNNTransposed": lib.hipSpMVRowsELLNNTransposed,
     "hipSpMVWarpsPerRowELLNTrasposed": lib.hipSpMVWarpsPerRowELLNTrasposed,

@@ -125,6 +125,7 @@ void freeDesc(DevMat* d) {
     }
     (void)hipFree(d->blkRow); (void)hipFree(d->blkInfo); (void)hipFree(d->blkBase);
     freeTiles(d->tiles);
+    freeSell(d->sell);
     d->magic = 0;
     delete d;
 }
@@ -591,6 +592,28 @@ int spmvHipBuildTiles(spmat* dMat) {
 size_t spmvHipTilesBytes(spmat* dMat) {
     DevMat* d = descOf(dMat, "spmvHipTilesBytes");
     return d ? tilesBytes(d) : 0;
+}
+
+int spmvHipBuildSell(spmat* dMat) {
+    DevMat* d = descOf(dMat, "spmvHipBuildSell");
+    if (!d) return EXIT_FAILURE;
+    if (d->kind != Kind::CSR) { ERR("spmvHipBuildSell: handle is not CSR"); return EXIT_FAILURE; }
+    return buildSell(d);
+}
+size_t spmvHipSellBytes(spmat* dMat) {
+    DevMat* d = descOf(dMat, "spmvHipSellBytes");
+    return d ? sellBytes(d) : 0;
+}
+int hipSpMVRowsSELL(spmat* dMat, double* dX, CONFIG cfg, double* dY) {
+    (void)cfg;
+    DevMat* d = descOf(dMat, "hipSpMVRowsSELL");
+    if (!d) return EXIT_FAILURE;
+    if (d->kind != Kind::CSR) { ERR("hipSpMVRowsSELL: handle is not CSR (the SELL-C-sigma copy is derived from an uploaded CSR)"); return EXIT_FAILURE; }
+    if (d->M == 0) return EXIT_SUCCESS;
+    if (!d->sell && buildSell(d)) return EXIT_FAILURE;
+    Launch L(grid2d((d->M + 255) / 256, 256), dim3(256));
+    if (enqueueSell(d, dX, dY, S.stream)) { ERR("hipSpMVRowsSELL: launch failed"); return EXIT_FAILURE; }
+    return L.finish("hipSpMVRowsSELL");
 }
 
 int hipSpMVTilesCSR(spmat* dMat, double* dX, CONFIG cfg, double* dY) {

@@ -26,6 +26,7 @@ constexpr uint64_t IRP32_LIMIT     = (1ull << 32) - 65536;
 enum class Kind : int { CSR = 0, ELL_ROWMAJOR = 1, ELL_COLMAJOR = 2 };
 
 struct TileFormat;          // column-sliced two-phase format, tiles.hip
+struct SellFormat;          // SELL-C-sigma, sell.hip
 
 struct DevMat {
     uint32_t magic = 0x53504D56;    // 'SPMV'
@@ -49,7 +50,13 @@ struct DevMat {
     uint64_t* blkBase = nullptr;    // nnz offset of the block
     uint32_t  nBlk2 = 0, nLong2 = 0;
     TileFormat* tiles = nullptr;    // built lazily by hipSpMVTilesCSR / spmvHipBuildTiles
+    SellFormat* sell = nullptr;     // built lazily by hipSpMVRowsSELL / spmvHipBuildSell
 };
+
+int  buildSell(DevMat* d);                                      // sell.hip
+void freeSell(SellFormat* f);
+int  enqueueSell(DevMat* d, const double* x, double* y, hipStream_t stream);
+size_t sellBytes(const DevMat* d);
 
 int  buildTiles(DevMat* d);                                     // tiles.hip
 void freeTiles(TileFormat* t);

@@ -90,7 +90,7 @@ def _run(api, launcher, dmat, x, rows):
 @pytest.mark.parametrize("launcher,variant,exact", [
     ("hipSpMVRowsCSR", 0, True), ("hipSpMVRowsCSR", 1, True), ("hipSpMVRowsCSR", 2, True),
     ("hipSpMVWarpPerRowCSR", 0, False), ("hipSpMVWarpPerRowCSR", 1, False), ("hipSpMVWarpPerRowCSR", 2, False),
-    ("hipSpMVTilesCSR", -1, False)])
+    ("hipSpMVTilesCSR", -1, False), ("hipSpMVRowsSELL", -1, False)])
 def test_csr(api, oracle, name, launcher, variant, exact):
     M, N, IRP, JA, AS = CASES[name]
     x = _x(np.random.default_rng(7), N)
@@ -100,6 +100,9 @@ def test_csr(api, oracle, name, launcher, variant, exact):
     if variant >= 0:
         api.set_variant(launcher, variant)
     y = _run(api, launcher, dmat, x, M)
+    if launcher == "hipSpMVRowsSELL":                   # one lane per row, ascending j: exact for rows <= 256 entries
+        short = np.diff(IRP.astype(np.int64)) <= 256
+        assert np.array_equal(y[short], y_ref[short])
     if launcher == "hipSpMVTilesCSR" and JA.size:       # second call re-uses the built format
         assert np.max(np.abs(_run(api, launcher, dmat, x, M) - y)) <= 1e-15    # arrival-order sums differ in the last bits
     dmat.free()
@@ -168,7 +171,7 @@ def test_synth_device_matches_twin_and_oracle(api, oracle):
             assert (d[mask] > 0).all() and ja_ref.max() < w.N
             x = synth.make_x(w.N, w.cfg)
             y_ref = oracle.csr_serial_dev(irp.astype(np.uint32), ja_ref, as_ref, x)
-            for launcher, exact in (("hipSpMVRowsCSR", True), ("hipSpMVWarpPerRowCSR", False), ("hipSpMVTilesCSR", False)):
+            for launcher, exact in (("hipSpMVRowsCSR", True), ("hipSpMVWarpPerRowCSR", False), ("hipSpMVTilesCSR", False), ("hipSpMVRowsSELL", False)):
                 y = _run(api, launcher, dm, x, w.N)
                 assert np.max(np.abs(y - y_ref)) <= GATE
                 if exact:
@@ -210,7 +213,8 @@ def test_full_size_spot_checks(api, oracle, key):
                                   dm.buffers["JA"].ptr.value + 4 * b0, 4 * (b1 - b0))
         assert np.array_equal(ja_dev, ja)
         refs.append(oracle.csr_serial_dev((irp[r0:r1 + 1] - irp[r0]).astype(np.uint32), ja, as_, x))
-    for launcher, exact in (("hipSpMVWarpPerRowCSR", False), ("hipSpMVRowsCSR", True), ("hipSpMVTilesCSR", False)):
+    for launcher, exact in (("hipSpMVWarpPerRowCSR", False), ("hipSpMVRowsCSR", True), ("hipSpMVTilesCSR", False),
+                            ("hipSpMVRowsSELL", False)):
         dy.poison()
         api.spmv(launcher, dm, dx, dy)
         y = dy.down()
@@ -266,7 +270,7 @@ def test_64bit_row_pointers_small(api, oracle):
     assert api.lib.spmvHipAdoptCSR(C.byref(dm.handle), M, N, JA.size, d_irp.ptr, 8, d_ja.ptr, d_as.ptr, None) == 0
     dm.keep = [d_irp, d_ja, d_as]
     for launcher, variants, exact in (("hipSpMVRowsCSR", (0, 1, 2), True), ("hipSpMVWarpPerRowCSR", (0, 1, 2), False),
-                                      ("hipSpMVTilesCSR", (-1,), False)):
+                                      ("hipSpMVTilesCSR", (-1,), False), ("hipSpMVRowsSELL", (-1,), False)):
         for v in variants:
             if v >= 0:
                 api.set_variant(launcher, v)

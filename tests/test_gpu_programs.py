@@ -20,7 +20,7 @@ HARNESS = os.path.join(ROOT, "tests", "harness", "test_SpMV_HIP.elf")
 
 
 @pytest.mark.parametrize("name", NAMES)
-@pytest.mark.parametrize("mode", ["CUDA_CSR_ROWS", "CUDA_CSR_ROWS_WARP", "HIP_CSR_TILES", "CUDA_ELL_ROWS",
+@pytest.mark.parametrize("mode", ["CUDA_CSR_ROWS", "CUDA_CSR_ROWS_WARP", "HIP_CSR_TILES", "HIP_SELL_ROWS", "CUDA_ELL_ROWS",
                                   "HIP_ELL_ROWS_NN_TRANSPOSED", "CUDA_ELL_ROWS_WARP_NN_TRANSPOSED"])
 def test_cli_against_reference_cli_output(name, mode):
     g = load_golden(name)
@@ -31,7 +31,7 @@ def test_cli_against_reference_cli_output(name, mode):
     y = np.fromfile("/tmp/outVectorDumpRaw")
     assert y.size == g["M"] and not np.isnan(y).any()
     assert np.max(np.abs(y - g["y_csr"]), initial=0) <= 7e-4
-    if mode in ("CUDA_CSR_ROWS", "CUDA_ELL_ROWS", "HIP_ELL_ROWS_NN_TRANSPOSED"):
+    if mode in ("CUDA_CSR_ROWS", "HIP_SELL_ROWS", "CUDA_ELL_ROWS", "HIP_ELL_ROWS_NN_TRANSPOSED"):
         assert np.max(np.abs(y - g["y_csr"]), initial=0) <= 1e-19       # ascending-j kernels: same bits up to simd re-association
     txt = np.loadtxt("/tmp/outVectorDump", ndmin=1)
     assert np.allclose(txt, y, rtol=1e-6, atol=0)
@@ -61,7 +61,7 @@ def test_harness_all_implementations_pass(name):
                        capture_output=True, text=True, timeout=300, env=dict(os.environ, OMP_NUM_THREADS="4"))
     assert r.returncode == 0, r.stdout + r.stderr
     out = r.stdout
-    assert out.count("cudaBlockSize:") == 6 and out.count("threadNum:") == 8     # 3 CSR + 3 ELL launchers; 5 + 3 OpenMP variants like the reference
+    assert out.count("cudaBlockSize:") == 7 and out.count("threadNum:") == 8     # 4 CSR-upload + 3 ELL launchers; 5 + 3 OpenMP variants like the reference
     assert "AVG_TIMES_ITERATION:25" in out and "MAX_ROW_NZ" in out and "omp sched gather:" in out
 
 
