@@ -24,7 +24,7 @@ $(PKG)/lib/libspmvhip.so: $(HIPSRC) $(HIPHDR)
 host: $(PKG)/lib/libspmvhost.so $(PKG)/bin/SpMV_HIP.elf
 $(PKG)/lib/libspmvhost.so: $(HOSTLIBSRC) $(wildcard include/*.h)
 	mkdir -p $(PKG)/lib
-	$(CC) $(CFLAGS) -shared -o $@ $(HOSTLIBSRC) -lm
+	$(CC) $(CFLAGS) -shared -o $@ $(HOSTLIBSRC) -lm -lz -ldl
 $(PKG)/bin/SpMV_HIP.elf: $(PKG)/csrc/host/main.c $(PKG)/lib/libspmvhost.so $(PKG)/lib/libspmvhip.so
 	mkdir -p $(PKG)/bin
 	$(CC) $(CFLAGS) -o $@ $(PKG)/csrc/host/main.c -L$(PKG)/lib -lspmvhost -lspmvhip -Wl,-rpath,'$$ORIGIN/../lib' -lm

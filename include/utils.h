@@ -2,7 +2,7 @@
  * utils.h -- vector I/O, run configuration from the environment, the parity
  * gate and timing statistics.  Surface of the reference's
  * src/include/utils.h:21-108 restricted to what the SpMV path uses
- * (shell-out decompression, utils.c:433-462, is out of scope).
+ * (compressed inputs are inflated in-process instead of through system()).
  */
 #ifndef SPMV_UTILS_H
 #define SPMV_UTILS_H
@@ -48,6 +48,11 @@ int doubleVectorsDiff(double* a, double* b, ulong n, double* diffMax);
 void statsAvgVar(double* values, uint numVals, double* out);
 
 void printVector(double* v, ulong size);
+
+/* Inflate a .gz / .bz2 MatrixMarket file into `tmpFsDecompressPath` (in-process; the
+ * reference shells out, utils.c:433-462).  0 = inflated, -1 = no compression suffix
+ * (open `path` itself), 1 = failed / unsupported (.xz, .zip). */
+int extractInTmpFS(char* path, char* tmpFsDecompressPath);
 
 #ifdef __cplusplus
 }

@@ -62,7 +62,13 @@ int main(int argc, char** argv) {
 
     if (spmvHipInit((int)envLong("SPMV_DEVICE", 0), sizeof(spmat), sizeof(CONFIG))) return out;
 
-    if (!(mat = toCSR ? MMtoCSR(argv[1]) : MMtoELL(argv[1]))) {
+    char* trgtMatPath = TMP_EXTRACTED_MARTIX;           /* compressed input -> scratch copy, like main.cu:141-142 */
+    {
+        const int ex = extractInTmpFS(argv[1], TMP_EXTRACTED_MARTIX);
+        if (ex < 0) trgtMatPath = argv[1];
+        else if (ex > 0) goto _free;
+    }
+    if (!(mat = toCSR ? MMtoCSR(trgtMatPath) : MMtoELL(trgtMatPath))) {
         ERRPRINTS("err during parsing MatrixMarket -> %s\n", toCSR ? "CSR" : "ELL");
         goto _free;
     }

@@ -15,6 +15,9 @@
 #include <sys/stat.h>
 #include <unistd.h>
 
+#include <dlfcn.h>
+#include <zlib.h>
+
 #include "utils.h"
 
 int urndFd = -1;
@@ -173,4 +176,56 @@ void statsAvgVar(double* values, uint numVals, double* out) {
 void printVector(double* v, ulong size) {
     for (ulong i = 0; i < size; ++i) printf("%1.1lf ", v[i]);
     printf("\n");
+}
+
+/* ---- compressed inputs ------------------------------------------
+ * The reference shells out: system("gzip -d -c <path> > <tmp>") etc. (utils.c:433-462).
+ * Here the file is inflated in-process: .gz through zlib, .bz2 through libbz2's
+ * high-level API resolved with dlopen (no bzlib.h in the image); .xz / .zip are
+ * reported as unsupported.  Returns 0 on success, -1 when `path` has no known
+ * compression suffix (caller then opens it as is), 1 on failure. */
+static int endsWith(const char* s, const char* suffix) {
+    const size_t a = strlen(s), b = strlen(suffix);
+    return a >= b && !strcmp(s + a - b, suffix);
+}
+
+int extractInTmpFS(char* path, char* tmpFsDecompressPath) {
+    const int gz = endsWith(path, ".gz"), bz = endsWith(path, ".bz2");
+    if (endsWith(path, ".xz") || endsWith(path, ".zip")) {
+        ERRPRINTS("NOT SUPPORTED DECOMPRESS FOR %s (only .gz and .bz2 are inflated in-process)\n", path);
+        return 1;
+    }
+    if (!gz && !bz) return -1;
+    FILE* out = fopen(tmpFsDecompressPath, "wb");
+    if (!out) { perror("fopen decompress target"); return 1; }
+    int rc = 1;
+    static char buf[1 << 16];
+    if (gz) {
+        gzFile in = gzopen(path, "rb");
+        if (!in) { perror("gzopen"); goto done; }
+        int n;
+        while ((n = gzread(in, buf, sizeof buf)) > 0)
+            if (fwrite(buf, 1, (size_t)n, out) != (size_t)n) { n = -1; break; }
+        rc = n < 0 ? 1 : 0;
+        if (gzclose(in) != Z_OK) rc = 1;
+    } else {
+        void* so = dlopen("libbz2.so.1.0", RTLD_NOW);
+        if (!so) so = dlopen("libbz2.so.1", RTLD_NOW);
+        if (!so) { ERRPRINTS("cannot load libbz2: %s\n", dlerror()); goto done; }
+        void* (*bzopen)(const char*, const char*) = (void* (*)(const char*, const char*))dlsym(so, "BZ2_bzopen");
+        int (*bzread)(void*, void*, int) = (int (*)(void*, void*, int))dlsym(so, "BZ2_bzread");
+        void (*bzclose)(void*) = (void (*)(void*))dlsym(so, "BZ2_bzclose");
+        void* in = bzopen && bzread && bzclose ? bzopen(path, "rb") : NULL;
+        if (!in) { ERRPRINTS("BZ2_bzopen failed for %s\n", path); dlclose(so); goto done; }
+        int n;
+        while ((n = bzread(in, buf, (int)sizeof buf)) > 0)
+            if (fwrite(buf, 1, (size_t)n, out) != (size_t)n) { n = -1; break; }
+        rc = n < 0 ? 1 : 0;
+        bzclose(in);
+        dlclose(so);
+    }
+done:
+    if (fclose(out)) rc = 1;
+    if (rc) ERRPRINTS("decompression of %s failed\n", path);
+    return rc;
 }

@@ -100,8 +100,14 @@ int main(int argc, char** argv) {
     spmat dMat;
     memset(&dMat, 0, sizeof dMat);
 
-    if (!(matCSR = MMtoCSR(argv[1]))) return out;
-    if (!(matELL = MMtoELL(argv[1]))) ERRPRINTS("ELL not feasible for %s:(", argv[1]);
+    char* trgtMatrix = TMP_EXTRACTED_MARTIX;            /* compressed input -> scratch copy (SpMV_test.cu:171-172) */
+    {
+        const int ex = extractInTmpFS(argv[1], TMP_EXTRACTED_MARTIX);
+        if (ex < 0) trgtMatrix = argv[1];
+        else if (ex > 0) return out;
+    }
+    if (!(matCSR = MMtoCSR(trgtMatrix))) return out;
+    if (!(matELL = MMtoELL(trgtMatrix))) ERRPRINTS("ELL not feasible for %s:(", argv[1]);
     spmat* mat = matCSR;
     ulong vectSize = mat->N;
     if (!strcmp(argv[2], RNDVECT)) {

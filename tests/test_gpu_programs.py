@@ -37,6 +37,16 @@ def test_cli_against_reference_cli_output(name, mode):
     assert np.allclose(txt, y, rtol=1e-6, atol=0)
 
 
+def test_cli_reads_gz(tmp_path):
+    import gzip
+    g = load_golden("sym6")
+    src = tmp_path / "sym6.mtx.gz"
+    src.write_bytes(gzip.compress(open(os.path.join(GOLD, "sym6.mtx"), "rb").read()))
+    r = subprocess.run([CLI, str(src), os.path.join(GOLD, "x_sym6.bin"), "CUDA_CSR_ROWS"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    assert np.max(np.abs(np.fromfile("/tmp/outVectorDumpRaw") - g["y_csr"])) <= 1e-19
+
+
 def test_cli_sharded_env():
     """SPMV_NGPU=1 drives the spmvHipShardCSR path from the CLI."""
     g = load_golden("rand300")

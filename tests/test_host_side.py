@@ -176,3 +176,25 @@ def test_powerlaw_law_and_permutation():
     # heavy rows are scattered, not clustered at the start
     heavy = np.nonzero(lens > 1000)[0]
     assert heavy.size > 5 and heavy.max() - heavy.min() > N // 2
+
+
+def test_compressed_inputs(tmp_path):
+    """.gz / .bz2 MatrixMarket files are inflated in-process (the reference shells out); .xz is refused."""
+    import bz2
+    import gzip
+    H.extractInTmpFS.argtypes = [C.c_char_p, C.c_char_p]
+    raw = open(os.path.join(GOLD, "cage4like.mtx"), "rb").read()
+    g = load_golden("cage4like")
+    for name, data in (("m.mtx.gz", gzip.compress(raw)), ("m.mtx.bz2", bz2.compress(raw))):
+        src = tmp_path / name
+        src.write_bytes(data)
+        dst = str(tmp_path / "extracted").encode()
+        assert H.extractInTmpFS(str(src).encode(), dst) == 0
+        assert open(dst, "rb").read() == raw
+        m = H.MMtoCSR(dst).contents
+        assert m.NZ == g["NZ"] and np.array_equal(_arr(m.JA, m.NZ, np.uint64), g["JA"])
+    plain = tmp_path / "p.mtx"
+    plain.write_bytes(raw)
+    assert H.extractInTmpFS(str(plain).encode(), str(tmp_path / "x").encode()) == -1      # not compressed
+    assert H.extractInTmpFS(b"/tmp/whatever.mtx.xz", str(tmp_path / "x").encode()) == 1     # unsupported
+    assert H.extractInTmpFS(b"/nonexistent/file.mtx.gz", str(tmp_path / "x").encode()) == 1
