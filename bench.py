@@ -171,6 +171,33 @@ def measure_single(api, synth, torch, w, launcher, steps, warmup, candidates=Non
     return res, dict(dm=dm, irp=irp, x_host=x_host, y=y, x=x, lens=lens)
 
 
+def oracle_spot_checks(synth, w, irp, x_host, y_gpu_fn, windows=None):
+    """GPU y against the serial oracle on 200 k-row windows (head, middle, tail by default); the rows are
+    regenerated by the CPU twin of the device generator.  Checker use of oracle/ (allowed for bench.py)."""
+    import numpy as np
+    ora = C.CDLL(os.path.join(ROOT, "oracle", "liboracle.so"))
+    vp = C.c_void_p
+    ora.synthFillCsrRef.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64, vp, vp, vp, C.c_uint64, C.c_uint64, C.c_uint64]
+    ora.oracleCsrSerial64_32.argtypes = [C.c_ulong, vp, vp, vp, vp, vp]
+    spot = []
+    for r0 in (windows if windows is not None else (0, w.N // 2, max(0, w.N - 200_000))):
+        r1 = min(w.N, r0 + 200_000)
+        irp_r = np.ascontiguousarray(irp[r0:r1 + 1], dtype=np.uint64)
+        nz = int(irp_r[-1] - irp_r[0])
+        jr = np.empty(nz, dtype=np.uint32)
+        ar = np.empty(nz, dtype=np.float64)
+        ora.synthFillCsrRef(r1 - r0, w.N, r0, irp_r.ctypes.data_as(vp), jr.ctypes.data_as(vp), ar.ctypes.data_as(vp),
+                            synth.SEED_STRUCT + w.cfg, synth.SEED_VAL + w.cfg, w.band)
+        yr = np.empty(r1 - r0)
+        irp_l = irp_r - irp_r[0]
+        ora.oracleCsrSerial64_32(r1 - r0, irp_l.ctypes.data_as(vp), jr.ctypes.data_as(vp), ar.ctypes.data_as(vp),
+                                 x_host.ctypes.data_as(vp), yr.ctypes.data_as(vp))
+        yg = y_gpu_fn(r0, r1)
+        spot.append({"rows": [int(r0), int(r1)], "max_abs_diff": float(np.max(np.abs(yr - yg))) if r1 > r0 else 0.0,
+                     "nan": bool(np.isnan(yg).any())})
+    return spot
+
+
 def cpu_baseline_and_check(api, synth, w, irp, x_host, y_gpu_fn, sample_nnz, iters=5):
     """Time the reference's spmvRowsBasicCSR (oracle/_ref) -- or the oracle port --
     on the first rows of the workload (<= sample_nnz nnz) with all host cores, and
@@ -230,23 +257,7 @@ def cpu_baseline_and_check(api, synth, w, irp, x_host, y_gpu_fn, sample_nnz, ite
                                x_host.ctypes.data_as(vp), y_cpu.ctypes.data_as(vp))
             times.append(time.perf_counter() - t0)
     # spot checks away from the head of the matrix (a wrapped grid or a wrong row-block table would show here)
-    spot = []
-    ora.oracleCsrSerial64_32.argtypes = [C.c_ulong, vp, vp, vp, vp, vp]
-    for r0 in (w.N // 2, max(0, w.N - 200_000)):
-        r1 = min(w.N, r0 + 200_000)
-        irp_r = np.ascontiguousarray(irp[r0:r1 + 1], dtype=np.uint64)
-        nz = int(irp_r[-1] - irp_r[0])
-        jr = np.empty(nz, dtype=np.uint32)
-        ar = np.empty(nz, dtype=np.float64)
-        ora.synthFillCsrRef(r1 - r0, w.N, r0, irp_r.ctypes.data_as(vp), jr.ctypes.data_as(vp), ar.ctypes.data_as(vp),
-                            synth.SEED_STRUCT + w.cfg, synth.SEED_VAL + w.cfg, w.band)
-        yr = np.empty(r1 - r0)
-        irp_l = irp_r - irp_r[0]
-        ora.oracleCsrSerial64_32(r1 - r0, irp_l.ctypes.data_as(vp), jr.ctypes.data_as(vp), ar.ctypes.data_as(vp),
-                                 x_host.ctypes.data_as(vp), yr.ctypes.data_as(vp))
-        yg = y_gpu_fn(r0, r1)
-        spot.append({"rows": [int(r0), int(r1)], "max_abs_diff": float(np.max(np.abs(yr - yg))),
-                     "nan": bool(np.isnan(yg).any())})
+    spot = oracle_spot_checks(synth, w, irp, x_host, y_gpu_fn, windows=(w.N // 2, max(0, w.N - 200_000)))
     times = times[1:]                                             # first pass = page-in
     t = sum(times) / len(times)
     y_gpu_head = y_gpu_fn(0, rows)
@@ -431,6 +442,7 @@ def main():
     dist.all_gather(chk_all, chk)
     same = all(torch.equal(c, chk_all[0]) for c in chk_all)
     if rank == 0:
+        spot = oracle_spot_checks(synth, w, irp, synth.make_x(w.N, w.cfg), lambda a, b: y[a:b].cpu().numpy())
         bytes_alg_local = synth.algorithmic_bytes_csr(nnz_local, r1 - r0, w.N)
         bytes_alg_total = synth.algorithmic_bytes_csr(nnz_total, w.N, w.N)
         k_avg = kernel_ms_max * 1e-3
@@ -451,7 +463,9 @@ def main():
                          "algorithmic_bytes_per_launch": bytes_alg_local,
                          "kernel_ms_avg": kernel_ms_max, "note": "per-rank kernels (all row groups), slowest rank"},
             "exposed_gather_ms_per_step": wall_max / steps * 1e3 - kernel_ms_max,
-            "parity": {"all_ranks_hold_identical_y": bool(same), "nan_left": float(chk_all[0][2])},
+            "parity": {"all_ranks_hold_identical_y": bool(same), "nan_left": float(chk_all[0][2]), "spot_checks": spot,
+                       "gate_abs": 7e-4, "ok": bool(same and float(chk_all[0][2]) == 0 and
+                                                    all(not c["nan"] and c["max_abs_diff"] <= 7e-4 for c in spot))},
         }
         emit(line)
     dist.barrier()
