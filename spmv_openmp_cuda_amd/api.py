@@ -14,7 +14,7 @@ import numpy as np
 from .ctypes_defs import CONFIG, POISON_NAN, SPMAT_TAG_ELL_TRANSPOSED, spmat, spmvDim3
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libspmvhip.so")
+LIB_PATH = os.environ.get("SPMV_LIB") or os.path.join(_HERE, "lib", "libspmvhip.so")      # SPMV_LIB: tuning builds only
 HOSTLIB_PATH = os.path.join(_HERE, "lib", "libspmvhost.so")
 
 

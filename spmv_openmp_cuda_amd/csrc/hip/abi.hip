@@ -669,7 +669,7 @@ int hipSpMVWarpsPerRowELLNTrasposed(spmat* dMat, double* dX, CONFIG cfg, double*
     // lanes per row: the smallest power of two covering the slots, 4..64
     int G = 4;
     while (G < WAVE && (uint64_t)G < d->K) G <<= 1;
-    const unsigned bt = WG_THREADS;
+    const unsigned bt = 256;
     (void)cfg;
     const uint64_t threads = (d->M + ELL_GROUP_ROWS - 1) / ELL_GROUP_ROWS * (uint64_t)G;     // a group of G lanes owns 4 rows
     const dim3 grid = grid2d((threads + bt - 1) / bt, bt), block(bt);

@@ -16,8 +16,14 @@
 namespace spmvhip {
 
 constexpr int      WAVE            = 64;
-constexpr int      WG_THREADS      = 256;      // 4 wavefronts
-constexpr int      STREAM_NNZ      = 2048;     // nnz staged in LDS per workgroup (16 KiB of fp64)
+#ifndef SPMV_WG_THREADS
+#define SPMV_WG_THREADS 256
+#endif
+#ifndef SPMV_STREAM_NNZ
+#define SPMV_STREAM_NNZ 2048
+#endif
+constexpr int      WG_THREADS      = SPMV_WG_THREADS;   // 4 wavefronts
+constexpr int      STREAM_NNZ      = SPMV_STREAM_NNZ;   // nnz staged in LDS per workgroup (16 KiB of fp64)
 constexpr uint32_t STREAM_MAX_ROWS = 2048;     // bounds a block made of empty / 1-nnz rows
 // 32-bit row pointers are used only below this nnz count, so that `j + stride`
 // in the kernels can never wrap around 2^32

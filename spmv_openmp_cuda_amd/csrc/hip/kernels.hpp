@@ -55,7 +55,7 @@ __device__ __forceinline__ double group_sum_rt(double v, int G) {
 // the LDS-stream kernel: lanes stride by the row length, so AS/JA reads are
 // uncoalesced.
 template <typename I>
-__global__ __launch_bounds__(WG_THREADS) void csr_scalar_kernel(
+__global__ __launch_bounds__(1024) void csr_scalar_kernel(
     uint32_t M, const I* __restrict__ IRP, const uint32_t* __restrict__ JA,
     const double* __restrict__ AS, const double* __restrict__ x, double* __restrict__ y) {
     const uint64_t gid = linear_block() * blockDim.x + threadIdx.x;
@@ -224,7 +224,7 @@ __global__ __launch_bounds__(WG_THREADS) void csr_stream_kernel(
 //  built and measured: on a +-512 band it is SLOWER, 0.80 vs 0.56 ms, because the window is reloaded
 //  per 2048-nnz block, costs a second barrier and halves occupancy, while the L1-resident gather it
 //  replaces already runs at ~1 lane/clk/CU.  Not kept)
-constexpr uint32_t STREAM2_MAX_ROWS = 512;
+constexpr uint32_t STREAM2_MAX_ROWS = 2 * WG_THREADS;     // two row pointers per lane
 
 template <typename I, bool SEQ>
 __global__ __launch_bounds__(WG_THREADS) void csr_stream2_kernel(
@@ -359,7 +359,7 @@ __global__ __launch_bounds__(WG_THREADS) void csr_stream2_kernel(
 // own length; otherwise walk all slots incl. the {AS=0,JA=0} padding exactly
 // like the reference kernel does.
 template <bool USE_RL>
-__global__ __launch_bounds__(WG_THREADS) void ell_colmajor_thread(
+__global__ __launch_bounds__(1024) void ell_colmajor_thread(
     uint32_t rows, uint32_t slots, size_t pitch, const uint32_t* __restrict__ JA,
     const double* __restrict__ AS, const uint32_t* __restrict__ RL,
     const double* __restrict__ x, double* __restrict__ y) {
@@ -385,7 +385,7 @@ __global__ __launch_bounds__(WG_THREADS) void ell_colmajor_thread(
 // Row-major + pitched, one thread per row (lane stride = pitch: uncoalesced by
 // construction -- the reference's slowest kernel, kept for the A/B).
 template <bool USE_RL>
-__global__ __launch_bounds__(WG_THREADS) void ell_rowmajor_thread(
+__global__ __launch_bounds__(1024) void ell_rowmajor_thread(
     uint32_t rows, uint32_t slots, size_t pitch, const uint32_t* __restrict__ JA,
     const double* __restrict__ AS, const uint32_t* __restrict__ RL,
     const double* __restrict__ x, double* __restrict__ y) {
@@ -407,7 +407,7 @@ __global__ __launch_bounds__(WG_THREADS) void ell_rowmajor_thread(
 constexpr int ELL_GROUP_ROWS = 4;
 
 template <bool USE_RL, int G>
-__global__ __launch_bounds__(WG_THREADS) void ell_rowmajor_group(
+__global__ __launch_bounds__(256) void ell_rowmajor_group(
     uint32_t rows, uint32_t slots, size_t pitch, const uint32_t* __restrict__ JA,
     const double* __restrict__ AS, const uint32_t* __restrict__ RL,
     const double* __restrict__ x, double* __restrict__ y) {

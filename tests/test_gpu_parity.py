@@ -351,3 +351,32 @@ def test_upload_validation_and_handle_lifecycle(api, capfd):
     api.set_variant("hipSpMVRowsCSR", 2)
     dmat.free()
     assert "not a multiple of the 64-lane wavefront" in capfd.readouterr().err
+
+
+def test_config_block_sizes(api, oracle):
+    """CONFIG.blockSize (the reference's BLOCKS_1D knob, config.h:102-105) up to 1024 threads on the
+    kernels that honour it."""
+    M, N, IRP, JA, AS = CASES["irregular"]
+    x = _x(np.random.default_rng(21), N)
+    y_ref = oracle.csr_serial(IRP, JA, AS, x)
+    host = api.HostCSR(M, N, IRP, JA, AS)
+    dcsr = api.spMatCpyCSR(host)
+    ell = host.to_ell()
+    dell_t, dell = api.spMatCpyELL(ell.transpose()), api.spMatCpyELL(ell)
+    dx, dy = api.DeviceVector(N).up(x), api.DeviceVector(M)
+    api.set_variant("hipSpMVRowsCSR", 0)
+    api.set_variant("hipSpMVWarpPerRowCSR", 0)
+    for bx in (64, 192, 512, 1024):
+        cfg = api.CONFIG()
+        cfg.blockSize.x = bx
+        for launcher, mat in (("hipSpMVRowsCSR", dcsr), ("hipSpMVWarpPerRowCSR", dcsr), ("hipSpMVRowsELL", dell_t),
+                              ("hipSpMVRowsELLNNTransposed", dell)):
+            dy.poison()
+            api.spmv(launcher, mat, dx, dy, cfg)
+            assert api.last_launch()[1][0] == bx
+            y = dy.down()
+            assert not np.isnan(y).any() and np.max(np.abs(y - y_ref)) <= GATE, (launcher, bx)
+    api.set_variant("hipSpMVRowsCSR", 2)
+    api.set_variant("hipSpMVWarpPerRowCSR", 2)
+    for m in (dcsr, dell_t, dell):
+        m.free()
