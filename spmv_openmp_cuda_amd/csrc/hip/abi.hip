@@ -22,7 +22,6 @@ struct State {
     bool        sync = true;
     int         variantRowsCSR = 2;     // 0 scalar, 1 LDS-stream SEQ (first generation), 2 second generation
     int         variantWarpCSR = 2;     // 0 wavefront-per-row, 1 LDS-stream VEC (first generation), 2 second generation
-    int         variantRowsEllNT = 0;
     bool        ellRowLens = true;
     double      lastSeconds = 0;
     spmvDim3    lastGrid{0, 0, 0}, lastBlock{0, 0, 0};
