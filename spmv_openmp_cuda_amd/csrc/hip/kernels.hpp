@@ -351,7 +351,10 @@ __global__ __launch_bounds__(WG_THREADS) void csr_stream2_kernel(
 //  register set while the current block is gathered and reduced -- was built and measured: 102 VGPRs
 //  -> 4 workgroups/CU, and slower everywhere (band 512: 0.83 vs 0.57 ms; serial-order variant 2.8 ms
 //  because long rows pin their workgroup).  With 8 resident workgroups per CU the hardware scheduler
-//  already overlaps the phases of different blocks.  Not kept)
+//  already overlaps the phases of different blocks.  Not kept; see DESIGN.md section 7.
+//  Also measured and dropped: lanes owning PAIRS of entries (16-B AS / 8-B JA loads from an even-aligned
+//  span start): 2-7 % slower on every workload (band 512: 0.582 vs 0.567 ms) -- fewer, wider vector loads
+//  do not help while the gather instructions dominate the memory pipe, and adjacent LDS stores conflict.)
 
 // ----------------------------------------------------------------------------------- ELL
 // Column-major ("transposed") + pitched, one thread per row: lane i of a wave
