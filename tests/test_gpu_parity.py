@@ -380,3 +380,29 @@ def test_config_block_sizes(api, oracle):
     api.set_variant("hipSpMVWarpPerRowCSR", 2)
     for m in (dcsr, dell_t, dell):
         m.free()
+
+
+def test_degenerate_shapes_all_launchers(api, oracle):
+    """1x1, a single empty row, a single column, rows >> cols: every CSR-upload launcher, no crash, exact zeros
+    where the row is empty."""
+    rng = np.random.default_rng(77)
+    shapes = {
+        "1x1": (1, 1, np.array([0, 1], dtype=np.uint64), np.array([0], dtype=np.uint64), np.array([2.5])),
+        "1x1-empty": (1, 1, np.array([0, 0], dtype=np.uint64), np.zeros(0, dtype=np.uint64), np.zeros(0)),
+        "one-column": (500, 1) + random_csr(rng, 500, 1, rng.integers(0, 2, size=500)),
+        "tall": (70000, 3) + random_csr(rng, 70000, 3, rng.integers(0, 4, size=70000)),
+    }
+    for name, (M, N, IRP, JA, AS) in shapes.items():
+        x = np.linspace(1e-5, 3e-5, N)
+        y_ref = oracle.csr_serial(IRP, JA, AS, x)
+        dm = api.spMatCpyCSR(api.HostCSR(M, N, IRP, JA, AS))
+        for launcher in ("hipSpMVRowsCSR", "hipSpMVWarpPerRowCSR", "hipSpMVTilesCSR", "hipSpMVRowsSELL"):
+            y = _run(api, launcher, dm, x, M)
+            assert not np.isnan(y).any(), (name, launcher)
+            assert np.max(np.abs(y - y_ref), initial=0.0) <= 1e-18, (name, launcher)
+        for transposed, launcher in ((True, "hipSpMVRowsELL"), (False, "hipSpMVWarpsPerRowELLNTrasposed")):
+            de = api.csr_to_ell_device(dm, transposed)
+            y = _run(api, launcher, de, x, M)
+            assert not np.isnan(y).any() and np.max(np.abs(y - y_ref), initial=0.0) <= 1e-18, (name, launcher)
+            de.free()
+        dm.free()
