@@ -52,7 +52,7 @@ def parse():
     p.add_argument("--no-extra", action="store_true", help="skip the secondary workloads measured at N=1")
     p.add_argument("--cpu-sample-nnz", type=int, default=100_000_000)
     p.add_argument("--groups", type=int, default=0,
-                   help="row groups per rank for kernel/all-gather overlap at N > 1 (0 = 4 at N=2, 2 at N>2)")
+                   help="row groups per rank for kernel/all-gather overlap at N > 1 (0 = measure 1/2[/4] and keep the fastest)")
     p.add_argument("--force-dist", action="store_true",
                    help="run the multi-rank code path (process group, all-gather) even with --gpus 1; for rehearsal")
     return p.parse_args()
@@ -387,32 +387,90 @@ def main():
 
     # ------------------------------------------------------------------ N > 1
     from spmv_openmp_cuda_amd import sharding
-    groups = args.groups if args.groups > 0 else (4 if world == 2 else 2 if world > 2 else 1)
     lens = synth.row_lengths(w)
     irp = synth.prefix(lens)
     info = synth.describe(w, lens)
     del lens
-    plan = sharding.make_plan(irp, world, groups)
-    r0, r1 = plan.rows(rank)
-    dms = [synth.device_csr(w, irp, *plan.block(rank, g)) for g in range(groups)]
     nnz_total = int(irp[-1])
-    nnz_local = int(irp[r1] - irp[r0])
     x_host = synth.make_x(w.N, w.cfg)
     x = torch.from_numpy(x_host).cuda()
-    del x_host
-    bufs = sharding.GatherBuffers(plan, rank, torch, "cuda")
-    # every rank must run the same kernel: rank 0 decides (on its first group)
-    launcher, tried = pick_launcher(api, torch, dms[0], x.data_ptr(), bufs.slot[0].data_ptr(), args.launcher)
+    cfg = api.CONFIG()
+
+    class Setup:
+        """this rank's `groups` row groups as device matrices + gather buffers"""
+        def __init__(self, groups):
+            self.groups = groups
+            self.plan = sharding.make_plan(irp, world, groups)
+            self.dms = [synth.device_csr(w, irp, *self.plan.block(rank, g)) for g in range(groups)]
+            self.bufs = sharding.GatherBuffers(self.plan, rank, torch, "cuda")
+
+        def warm(self, fn):                         # builds the per-group formats outside any timed region
+            for g, dm in enumerate(self.dms):
+                if fn(C.byref(dm.handle), x.data_ptr(), cfg, self.bufs.slot[g].data_ptr()):
+                    raise RuntimeError("launcher failed")
+            torch.cuda.synchronize()
+
+        def step(self, fn, ev=None):
+            def compute_group(g, slot):
+                if ev:
+                    api.lib.spmvHipEventRecord(ev[g][0])
+                rc = fn(C.byref(self.dms[g].handle), x.data_ptr(), cfg, slot.data_ptr())
+                if ev:
+                    api.lib.spmvHipEventRecord(ev[g][1])
+                if rc:
+                    raise RuntimeError("launcher failed")
+            # kernel(g) -> async RCCL all-gather(g) over xGMI (overlaps group g+1), then compaction
+            return sharding.step(self.plan, dist, self.bufs, compute_group)
+
+        def free(self):
+            for dm in self.dms:
+                dm.free()
+            self.dms, self.bufs = [], None
+
+    # every rank must run the same kernel: rank 0 decides (on its first group of the 1-group setup)
+    setup = Setup(1)
+    launcher, tried = pick_launcher(api, torch, setup.dms[0], x.data_ptr(), setup.bufs.slot[0].data_ptr(), args.launcher)
     choice = torch.tensor([AUTO_CANDIDATES.index(launcher) if launcher in AUTO_CANDIDATES else -1], device="cuda")
     dist.broadcast(choice, 0)
     if int(choice) >= 0:
         launcher = AUTO_CANDIDATES[int(choice)]
     fn = api.SPMV_LAUNCHERS[launcher]
-    cfg = api.CONFIG()
-    for dm in dms:                                  # build per-group formats outside the timed region
-        if fn(C.byref(dm.handle), x.data_ptr(), cfg, bufs.slot[dms.index(dm)].data_ptr()):
-            raise RuntimeError(launcher + " failed")
-    torch.cuda.synchronize()
+
+    # row groups per rank: more groups overlap more of the gather but make every group's kernels less
+    # efficient; which wins depends on the xGMI gather rate, so it is MEASURED: whole steps (kernels +
+    # gather + compaction), slowest rank, 3 steps per candidate
+    group_ms = {}
+    if args.groups > 0:
+        candidates = [args.groups]
+    else:
+        candidates = [1, 2, 4] if world == 2 else [1, 2]
+    best = None
+    for G in candidates:
+        cand = setup if G == 1 else Setup(G)
+        cand.warm(fn)
+        cand.step(fn)
+        dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            cand.step(fn)
+        torch.cuda.synchronize()
+        tt = torch.tensor([(time.perf_counter() - t0) / 3 * 1e3], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        group_ms[G] = float(tt[0])
+        if best is None or group_ms[G] < group_ms[best.groups]:
+            if best is not None:
+                best.free()
+            best = cand
+        else:
+            cand.free()
+        torch.cuda.empty_cache()
+    if setup is not best and setup.dms:
+        setup.free()
+    setup = best
+    groups, plan, bufs, dms = setup.groups, setup.plan, setup.bufs, setup.dms
+    r0, r1 = plan.rows(rank)
+    nnz_local = int(irp[r1] - irp[r0])
     evs = [[(C.c_void_p(), C.c_void_p()) for _ in range(groups)] for _ in range(steps)]
     for per_step in evs:
         for a, b in per_step:
@@ -420,15 +478,7 @@ def main():
             api.lib.spmvHipEventCreate(C.byref(b))
 
     def step(ev):
-        def compute_group(g, slot):
-            if ev:
-                api.lib.spmvHipEventRecord(ev[g][0])
-            rc = fn(C.byref(dms[g].handle), x.data_ptr(), cfg, slot.data_ptr())
-            if ev:
-                api.lib.spmvHipEventRecord(ev[g][1])
-            if rc:
-                raise RuntimeError(launcher + " failed")
-        sharding.step(plan, dist, bufs, compute_group)   # kernel(g) -> async RCCL all-gather(g) over xGMI, then compaction
+        setup.step(fn, ev)
 
     wall = time_kernel_loop(api, torch, dist, world, step, steps, warmup, evs)
     kms = [sum(kernel_ms(api, per_step)) for per_step in evs]
@@ -442,7 +492,7 @@ def main():
     dist.all_gather(chk_all, chk)
     same = all(torch.equal(c, chk_all[0]) for c in chk_all)
     if rank == 0:
-        spot = oracle_spot_checks(synth, w, irp, synth.make_x(w.N, w.cfg), lambda a, b: y[a:b].cpu().numpy())
+        spot = oracle_spot_checks(synth, w, irp, x_host, lambda a, b: y[a:b].cpu().numpy())
         bytes_alg_local = synth.algorithmic_bytes_csr(nnz_local, r1 - r0, w.N)
         bytes_alg_total = synth.algorithmic_bytes_csr(nnz_total, w.N, w.N)
         k_avg = kernel_ms_max * 1e-3
@@ -451,7 +501,7 @@ def main():
             "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": wall_max / steps * 1e3,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": info["workload"], **{k: v for k, v in info.items() if k != "workload"},
-                       "kernel": launcher, "auto_candidates_ms": tried,
+                       "kernel": launcher, "auto_candidates_ms": tried, "row_groups_step_ms": group_ms,
                        "parallelism": f"{world} ranks x {groups} nnz-balanced row groups; per group: kernel then async "
                                       f"RCCL all-gather(y) overlapping the next group" +
                                       ("" if plan.equal_blocks else "; padded blocks + compaction")},
