@@ -294,9 +294,14 @@ int buildTiles(DevMat* d) {
     if (S64 > 65535) { fprintf(stderr, "libspmvhip: tiles: %lu columns exceed 65535 slices\n", (unsigned long)N); return EXIT_FAILURE; }
     TileFormat* t = new TileFormat;
     t->S = (uint32_t)S64;
-    // rows per bin: as large as LDS allows, but keep >= ~1024 bins so phase 2 fills the chip
+    // rows per bin: as large as LDS allows (longer tiles = longer contiguous runs in phase 2); halve it while
+    // there are fewer than ~1024 bins (phase 2 should fill the chip several times over) AND the tiles would
+    // still average >= 64 entries.  Measured: c3 (10 M x 10 M) 8 Ki rows 1.27 ms vs 16 Ki 1.35 ms; a
+    // 10 M x 80 M shard of c5 16 Ki 1.44 ms, 8 Ki 1.50 ms, 4 Ki 1.95 ms.
     uint32_t rShift = PB_R_MAX_SHIFT;
-    while (rShift > 10 && (M >> rShift) < 1024) --rShift;
+    auto binsAt = [&](uint32_t sh) { return (M + (1ull << sh) - 1) >> sh; };
+    while (rShift > 10 && binsAt(rShift) < 1024 && nnz / ((uint64_t)t->S * binsAt(rShift - 1)) >= 64) --rShift;
+    if (const char* e = getenv("SPMV_PB_RSHIFT")) { const int v = atoi(e); if (v >= 10 && v <= (int)PB_R_MAX_SHIFT) rShift = (uint32_t)v; }   // tuning only
     t->rShift = rShift;
     t->B = (uint32_t)((M + (1ull << rShift) - 1) >> rShift);
     t->nnz = nnz;
