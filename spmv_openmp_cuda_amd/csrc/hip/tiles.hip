@@ -365,9 +365,16 @@ int buildTiles(DevMat* d) {
     std::vector<uint32_t> sliceStart(t->S + 1);
     PB_TRY(hipMemcpy2D(sliceStart.data(), 4, tileStart.as<uint32_t>(), (size_t)t->B * 4, 4, t->S + 1, hipMemcpyDeviceToHost));
     std::vector<uint3> work;
-    for (uint32_t s = 0; s < t->S; ++s)
-        for (uint32_t b = sliceStart[s]; b < sliceStart[s + 1]; b += PB_CHUNK)
-            work.push_back(make_uint3(s, b, std::min<uint32_t>(b + PB_CHUNK, sliceStart[s + 1])));
+    for (uint32_t s = 0; s < t->S; ++s) {
+        // a slice is cut into equal pieces of at most PB_CHUNK entries (multiples of 4 keep the vector loads aligned);
+        // a fixed chunk size + remainder left one short, fill-dominated work item per slice
+        const uint32_t b0 = sliceStart[s], len = sliceStart[s + 1] - b0;
+        if (!len) continue;
+        const uint32_t pieces = (len + PB_CHUNK - 1) / PB_CHUNK;
+        const uint32_t piece = ((len + pieces - 1) / pieces + 3) & ~3u;
+        for (uint32_t b = b0; b < b0 + len; b += piece)
+            work.push_back(make_uint3(s, b, std::min<uint32_t>(b + piece, b0 + len)));
+    }
     t->nWork = (uint32_t)work.size();
     PB_TRY(hipMalloc(&t->work, std::max<size_t>(work.size(), 1) * sizeof(uint3)));
     PB_TRY(hipMemcpy(t->work, work.data(), work.size() * sizeof(uint3), hipMemcpyHostToDevice));
