@@ -15,7 +15,7 @@ prof c5 --workload c5
 prof c3 --workload c3
 prof c3_onepass --workload c3 --launcher hipSpMVWarpPerRowCSR
 prof c3n --workload c3n --launcher hipSpMVWarpPerRowCSR
-prof c2 --workload c2 --launcher hipSpMVRowsCSR
+prof c2 --workload c2 --launcher hipSpMVRowsSELL
 timeout -k 10 600 python3 scripts/config4_ell.py > $O/config4_ell.md 2>/dev/null
 timeout -k 10 600 python3 scripts/config4_ell.py 1.0 512 > $O/config4_ell_band512.md 2>/dev/null
 ls $O
