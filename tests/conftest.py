@@ -18,9 +18,11 @@ def _ensure_built():
     """Build what is missing (no-op when the .so files travelled with the snapshot)."""
     need = [os.path.join(ROOT, "spmv_openmp_cuda_amd", "lib", "libspmvhip.so"),
             os.path.join(ROOT, "spmv_openmp_cuda_amd", "lib", "libspmvhost.so"),
-            os.path.join(ROOT, "oracle", "liboracle.so")]
+            os.path.join(ROOT, "spmv_openmp_cuda_amd", "bin", "SpMV_HIP.elf"),
+            os.path.join(ROOT, "oracle", "liboracle.so"),
+            os.path.join(ROOT, "tests", "harness", "test_SpMV_HIP.elf")]
     if not all(os.path.exists(p) for p in need):
-        subprocess.check_call(["make", "-C", ROOT, "lib", "host", "oracle"], stdout=subprocess.DEVNULL)
+        subprocess.check_call(["make", "-C", ROOT, "lib", "host", "oracle", "harness"], stdout=subprocess.DEVNULL)
 
 
 _ensure_built()
