@@ -66,8 +66,18 @@ def partition_by_nnz(irp, parts):
     return bounds
 
 
-def make_plan(irp, world, groups=1):
-    bounds = partition_by_nnz(irp, world * groups)
+def make_plan(irp, world, groups=1, snap_tol=0.01):
+    """nnz-balanced bounds; when cutting the rows into EQUAL blocks is just as balanced (largest block within
+    `snap_tol` of the mean nnz -- true for matrices whose heavy rows are scattered) the equal cut is used instead:
+    with one group per rank the gather buffer then IS y and no compaction pass is needed."""
+    parts = world * groups
+    bounds = partition_by_nnz(irp, parts)
+    M = len(irp) - 1
+    if snap_tol and M % parts == 0 and M > 0:
+        eq = np.arange(parts + 1, dtype=np.int64) * (M // parts)
+        share = np.diff(np.asarray(irp)[eq].astype(np.int64))
+        if share.max() <= (1.0 + snap_tol) * share.mean():
+            bounds = eq
     d = np.diff(bounds).reshape(world, groups)
     return ShardPlan(world, groups, bounds, [int(d[:, g].max()) for g in range(groups)])
 

@@ -152,6 +152,16 @@ def test_partition_rows_balances_nnz():
         assert b[0] == 0 and b[-1] == w.N and (np.diff(b) >= 0).all()
         share = np.diff(irp[b].astype(np.int64))
         assert share.sum() == w.nnz and np.abs(share - w.nnz / parts).max() <= 5000 + 1
+    # equal-row snap: scattered heavy rows -> equal blocks are nnz-balanced within 1 % and are preferred
+    w2 = synth.Workload("p", 64_000, 1_280_000, "powerlaw", 200, 9)
+    irp2 = synth.prefix(synth.row_lengths(w2))
+    plan = sharding.make_plan(irp2, 8)
+    assert plan.equal_blocks and (np.diff(plan.bounds) == 8000).all()
+    share = np.diff(irp2[plan.bounds].astype(np.int64))
+    assert share.max() <= 1.01 * share.mean()
+    assert not sharding.make_plan(irp2, 8, snap_tol=0).equal_blocks            # pure nnz split keeps its ragged blocks
+    skew = np.concatenate([np.full(100, 1000), np.ones(63_900)]).astype(np.uint32)   # heavy rows clustered: no snap
+    assert not sharding.make_plan(synth.prefix(skew), 8).equal_blocks
     # degenerate: more parts than rows, empty matrix
     irp2 = np.array([0, 5, 5, 9], dtype=np.uint64)
     b = api.partition_rows(irp2, 8)
