@@ -10,9 +10,13 @@
 //            x slice in LDS (128 KiB), streams {value, 16-bit local column} and
 //            writes the products back in the same order (coalesced).
 //   phase 2  pb_reduce : a workgroup owns a bin of R consecutive rows whose partial
-//            sums live in LDS (R x 8 B); it walks the bin's tile list
-//            (slice 0..S-1; each tile is a contiguous run of the product array),
-//            adds products with ds_add_f64 and finally stores the bin of y.
+//            sums live in LDS (R x 8 B).  The bin's entries, taken tile by tile
+//            (slice 0..S-1), form one dense BIN-MAJOR index space: the 16-bit local
+//            rows are stored in that order and stream in; every lane maps its
+//            bin-major position to the slice-major position of the product through
+//            the bin's tile table (start, offset), so the products are read as runs
+//            of one tile each with all 64 lanes busy; ds_add_f64 into LDS, and the
+//            bin of y is stored at the end.
 // ~28-30 B/nnz of pure streaming instead of 12 B/nnz + one line per nnz.  Measured ceilings on
 // the box (scripts/microbench_copy.hip): a 10 B read : 8 B write stream runs at 5.0 TB/s, a pure
 // read stream at 6.5 TB/s -> phase 1 >= 5.8 ms and phase 2 >= ~3.4 ms for 1.6 G nnz.
@@ -51,11 +55,13 @@ struct TileFormat {
     uint32_t S = 0, B = 0, rShift = 0;              // slices, bins, log2(rows per bin)
     uint64_t nnz = 0;
     double*   val = nullptr;                        // slice-major values
-    uint16_t* lcol = nullptr;                       // column - slice*PB_C
-    uint16_t* lrow = nullptr;                       // row - bin*R
-    uint2*    desc = nullptr;                       // per bin: {start, len <= PB_SPLIT} runs of the slice-major arrays
-    uint32_t* binDesc = nullptr;                    // [B+1] first descriptor of each bin
-    uint32_t  nDesc = 0;
+    uint16_t* lcol = nullptr;                       // slice-major: column - slice*PB_C
+    uint16_t* lrow = nullptr;                       // BIN-major: row - bin*R
+    uint2*    tl = nullptr;                         // non-empty tiles in bin-major order: {first bin-major position,
+                                                    // slice-major start - bin-major start (mod 2^32)}; sentinels follow
+    uint32_t  nList = 0;
+    uint32_t* binPos = nullptr;                     // [B+1] bin-major position where each bin starts
+    uint32_t* waveTile = nullptr;                   // [B * waves] tile-list index where each wavefront of phase 2 starts
     uint3*    work = nullptr;                       // phase-1 work items {slice, begin, end}
     uint32_t  nWork = 0;
     double*   prod = nullptr;                       // products, slice-major (workspace)
@@ -83,22 +89,14 @@ __global__ __launch_bounds__(256) void pb_keys_kernel(uint64_t nnz, const uint32
     idx[j] = (uint32_t)j;
 }
 
-// permute into slice-major order and mark where each tile starts.  tile id t = slice*B + bin is
-// non-decreasing along the sorted order, so the first entry of a tile also fills the start of
-// every empty tile before it.
-__global__ __launch_bounds__(256) void pb_gather_kernel(
-    uint64_t nnz, const uint32_t* __restrict__ perm, const uint16_t* __restrict__ skeys,
-    const uint32_t* __restrict__ rowOf, const uint32_t* __restrict__ JA, const double* __restrict__ AS,
-    uint32_t B, uint32_t rShift, uint64_t nTiles, double* __restrict__ val, uint16_t* __restrict__ lcol,
-    uint16_t* __restrict__ lrow, uint32_t* __restrict__ tileStart) {
+// mark where each tile starts in the sorted (slice-major) order.  tile id t = slice*B + bin is non-decreasing
+// along that order, so the first entry of a tile also fills the start of every empty tile before it.
+__global__ __launch_bounds__(256) void pb_bounds_kernel(
+    uint64_t nnz, const uint32_t* __restrict__ perm, const uint16_t* __restrict__ skeys, const uint32_t* __restrict__ rowOf,
+    uint32_t B, uint32_t rShift, uint64_t nTiles, uint32_t* __restrict__ tileStart) {
     const uint64_t p = lin_block() * 256 + threadIdx.x;
     if (p >= nnz) return;
-    const uint32_t j = perm[p];
-    const uint32_t row = rowOf[j];
-    val[p] = AS[j];
-    lcol[p] = (uint16_t)(JA[j] & (PB_C - 1));
-    lrow[p] = (uint16_t)(row & ((1u << rShift) - 1));
-    const uint64_t t = (uint64_t)skeys[p] * B + (row >> rShift);
+    const uint64_t t = (uint64_t)skeys[p] * B + (rowOf[perm[p]] >> rShift);
     uint64_t tPrev;                                  // tile of the previous entry, or "-1"
     if (p == 0) tPrev = ~0ull;
     else tPrev = (uint64_t)skeys[p - 1] * B + (rowOf[perm[p - 1]] >> rShift);
@@ -106,6 +104,51 @@ __global__ __launch_bounds__(256) void pb_gather_kernel(
         for (uint64_t u = tPrev + 1; u <= t; ++u) tileStart[u] = (uint32_t)p;      // tPrev+1 wraps to 0 for p == 0
     if (p == nnz - 1)
         for (uint64_t u = t + 1; u <= nTiles; ++u) tileStart[u] = (uint32_t)nnz;
+}
+
+// tile lengths in BIN-major order (i = bin*S + slice); their exclusive scan is every tile's bin-major start
+__global__ __launch_bounds__(256) void pb_lens_kernel(uint32_t S, uint32_t B, const uint32_t* __restrict__ tileStart,
+                                                      uint32_t* __restrict__ lens, uint32_t* __restrict__ flags) {
+    const uint64_t i = lin_block() * 256 + threadIdx.x;
+    if (i >= (uint64_t)S * B) return;
+    const uint32_t b = (uint32_t)(i / S), s = (uint32_t)(i % S);
+    const uint64_t t = (uint64_t)s * B + b;
+    const uint32_t len = tileStart[t + 1] - tileStart[t];
+    lens[i] = len;
+    flags[i] = len != 0;
+}
+
+// the list of non-empty tiles in bin-major order + where each bin starts
+__global__ __launch_bounds__(256) void pb_list_kernel(uint32_t S, uint32_t B, uint64_t nnz, const uint32_t* __restrict__ tileStart,
+                                                      const uint32_t* __restrict__ lens, const uint32_t* __restrict__ bmStart,
+                                                      const uint32_t* __restrict__ listIdx, uint32_t nList,
+                                                      uint2* __restrict__ tl,
+                                                      uint32_t* __restrict__ binPos, uint32_t* __restrict__ binTile) {
+    const uint64_t i = lin_block() * 256 + threadIdx.x;
+    if (i >= (uint64_t)S * B) return;
+    const uint32_t b = (uint32_t)(i / S), s = (uint32_t)(i % S);
+    if (lens[i]) {
+        const uint64_t t = (uint64_t)s * B + b;
+        tl[listIdx[i]] = make_uint2(bmStart[i], tileStart[t] - bmStart[i]);
+    }
+    if (s == 0) { binPos[b] = bmStart[i]; binTile[b] = listIdx[i]; }
+    if (i + 1 == (uint64_t)S * B) { binPos[B] = (uint32_t)nnz; binTile[B] = nList; }
+}
+
+// permute the values and local columns into slice-major order, the local rows into bin-major order
+__global__ __launch_bounds__(256) void pb_gather_kernel(
+    uint64_t nnz, const uint32_t* __restrict__ perm, const uint16_t* __restrict__ skeys,
+    const uint32_t* __restrict__ rowOf, const uint32_t* __restrict__ JA, const double* __restrict__ AS,
+    uint32_t S, uint32_t B, uint32_t rShift, const uint32_t* __restrict__ tileStart, const uint32_t* __restrict__ bmStart,
+    double* __restrict__ val, uint16_t* __restrict__ lcol, uint16_t* __restrict__ lrow) {
+    const uint64_t p = lin_block() * 256 + threadIdx.x;
+    if (p >= nnz) return;
+    const uint32_t j = perm[p];
+    const uint32_t row = rowOf[j], bin = row >> rShift, slice = skeys[p];
+    val[p] = AS[j];
+    lcol[p] = (uint16_t)(JA[j] & (PB_C - 1));
+    const uint32_t within = (uint32_t)p - tileStart[(uint64_t)slice * B + bin];
+    lrow[bmStart[(uint64_t)bin * S + slice] + within] = (uint16_t)(row & ((1u << rShift) - 1));
 }
 
 __global__ __launch_bounds__(256) void pb_fill_kernel(uint32_t* p, uint64_t n, uint32_t v) {
@@ -135,6 +178,21 @@ __device__ __forceinline__ void p1_load(P1Regs& r, uint32_t p, uint32_t ve, cons
             r.b[u] = __builtin_nontemporal_load((const dbl2*)(val + q + 2));
             r.c[u] = __builtin_nontemporal_load((const ush4*)(lcol + q));
         } else { r.a[u] = 0; r.b[u] = 0; r.c[u] = 0; }
+    }
+}
+
+__device__ __forceinline__ void p1_store(const P1Regs& r, uint32_t p, uint32_t ve, const double* xs, double* __restrict__ prod) {
+    constexpr uint32_t STEP = 4 * PB_THREADS;
+#pragma unroll
+    for (int u = 0; u < P1_DEPTH; ++u) {
+        const uint32_t q = p + u * STEP;
+        if (q < ve) {
+            dbl2 r0, r1;
+            r0.x = r.a[u].x * xs[r.c[u].x]; r0.y = r.a[u].y * xs[r.c[u].y];
+            r1.x = r.b[u].x * xs[r.c[u].z]; r1.y = r.b[u].y * xs[r.c[u].w];
+            __builtin_nontemporal_store(r0, (dbl2*)(prod + q));
+            __builtin_nontemporal_store(r1, (dbl2*)(prod + q + 2));
+        }
     }
 }
 
@@ -171,68 +229,95 @@ __global__ __launch_bounds__(PB_THREADS) void pb_expand_kernel(
 
     for (; p < ve; p += P1_DEPTH * STEP) {
         p1_load(nxt, p + P1_DEPTH * STEP, ve, val, lcol);
-#pragma unroll
-        for (int u = 0; u < P1_DEPTH; ++u) {
-            const uint32_t q = p + u * STEP;
-            if (q < ve) {
-                dbl2 r0, r1;
-                r0.x = cur.a[u].x * xs[cur.c[u].x]; r0.y = cur.a[u].y * xs[cur.c[u].y];
-                r1.x = cur.b[u].x * xs[cur.c[u].z]; r1.y = cur.b[u].y * xs[cur.c[u].w];
-                __builtin_nontemporal_store(r0, (dbl2*)(prod + q));
-                __builtin_nontemporal_store(r1, (dbl2*)(prod + q + 2));
-            }
-        }
+        p1_store(cur, p, ve, xs, prod);
         cur = nxt;
     }
 }
 
 // ---- phase 2 -----------------------------------------------------------------------------------
-// A bin's work is a list of descriptors {start, len <= PB_SPLIT}: the bin's non-empty tiles in
-// slice order, long tiles cut into pieces.  Each wavefront takes 64 consecutive descriptors at a
-// time (coalesced load, walked with shuffles) and keeps two groups of GROUP runs in flight:
-// the loads of the next group are issued before the LDS atomics of the current one.
-constexpr uint32_t PB_SPLIT = 64;                   // entries per descriptor = one wavefront-wide access
-constexpr int      GROUP    = 8;
+// The bin's entries are the bin-major positions [binPos[bin], binPos[bin+1]); each of the 16 wavefronts owns a
+// contiguous sub-range and walks it 64 positions at a time.  Position v belongs to the tile k with
+// tl[k].start <= v < tl[k+1].start; its product sits at slice-major position v + tl[k].delta.  The walk through
+// the tile table is wavefront-uniform, so it runs on the SCALAR unit: records come in through s_load (scalar
+// cache, lgkmcnt) two tiles ahead of their use, the per-lane choice is one v_cndmask per tile boundary, and the
+// vector memory pipeline carries nothing but the two streams.  (Keeping a window of records in vector registers,
+// refilled with a vector load inside the loop, made the compiler wait for ALL outstanding loads at every step
+// -- vmcnt is in-order -- and ran 34 % slower than the descriptor version this replaces.)
+// Two batches of P2_DEPTH steps are in flight: the loads of the next batch are issued before the LDS atomics
+// of the current one.
+#ifndef SPMV_P2_DEPTH
+#define SPMV_P2_DEPTH 8
+#endif
+constexpr int      P2_DEPTH = SPMV_P2_DEPTH;
+constexpr uint32_t P2_WAVES = PB_THREADS / 64;
+constexpr uint16_t P2_NONE  = 0xFFFF;               // "no entry" (local rows are < 2^14)
+constexpr uint32_t TL_PAD   = 4;                    // sentinel records behind the list (the cursor reads 2 ahead)
 
-struct RunRegs { double pv[GROUP]; uint16_t rv[GROUP]; uint32_t ln[GROUP]; };
+__host__ __device__ __forceinline__ uint32_t p2_sub(uint32_t len) { return ((len + P2_WAVES - 1) / P2_WAVES + 63u) & ~63u; }
 
-__device__ __forceinline__ void pb_fetch(RunRegs& r, uint2 mine, uint32_t t, uint32_t cnt, uint32_t lane,
-                                         const double* __restrict__ prod, const uint16_t* __restrict__ lrow) {
+struct P2Regs { double pv[P2_DEPTH]; uint16_t rv[P2_DEPTH]; };
+struct P2Cursor { uint32_t k, delta; uint2 n1, n2; };            // all wavefront-uniform: tile k, its delta, records k+1, k+2
+
+__device__ __forceinline__ void p2_fetch(P2Regs& r, P2Cursor& c, uint32_t vbase, uint32_t we, uint32_t lane,
+                                         const uint2* __restrict__ tl, const double* __restrict__ prod,
+                                         const uint16_t* __restrict__ lrow) {
+    // No branch around the loads: positions past the end are clamped to the last entry (a valid, already cached
+    // address) and marked P2_NONE afterwards, so the compiler can count the outstanding loads exactly and
+    // waits only for the batch it consumes (with the loads under `if` it fell back to vmcnt(0) everywhere).
 #pragma unroll
-    for (int q = 0; q < GROUP; ++q) {
-        const uint32_t st = __shfl(mine.x, (int)((t + q) & 63));
-        const uint32_t ln = (t + q < cnt) ? __shfl(mine.y, (int)((t + q) & 63)) : 0u;
-        r.ln[q] = ln;
-        const bool in = lane < ln;
-        r.pv[q] = in ? __builtin_nontemporal_load(prod + st + lane) : 0.0;
-        r.rv[q] = in ? __builtin_nontemporal_load(lrow + st + lane) : (uint16_t)0;
+    for (int u = 0; u < P2_DEPTH; ++u) {
+        const uint32_t vs = vbase + 64u * u;
+        const uint32_t v = vs + lane, vlast = min(vs + 63u, we - 1u);
+        uint32_t d = c.delta;
+        while (c.n1.x <= vlast) {                    // the next tile starts inside this step
+            d = (v >= c.n1.x) ? c.n1.y : d;
+            c.delta = c.n1.y;
+            c.n1 = c.n2;
+            ++c.k;
+            c.n2 = tl[c.k + 2];
+        }
+        const uint32_t vc = min(v, we - 1u);
+        r.pv[u] = __builtin_nontemporal_load(prod + (uint32_t)(vc + d));
+        const uint16_t row = __builtin_nontemporal_load(lrow + vc);
+        r.rv[u] = v < we ? row : P2_NONE;
     }
 }
 
 __global__ __launch_bounds__(PB_THREADS) void pb_reduce_kernel(
-    uint32_t rShift, uint64_t M, const uint32_t* __restrict__ binDesc, const uint2* __restrict__ desc,
-    const double* __restrict__ prod, const uint16_t* __restrict__ lrow, double* __restrict__ y) {
+    uint32_t rShift, uint64_t M, const uint32_t* __restrict__ binPos, const uint32_t* __restrict__ waveTile,
+    const uint2* __restrict__ tl, const double* __restrict__ prod, const uint16_t* __restrict__ lrow,
+    double* __restrict__ y) {
     extern __shared__ double yb[];                  // R doubles
     const uint32_t R = 1u << rShift;
     const uint64_t bin = lin_block();
+    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x / 64)), lane = threadIdx.x % 64;
+    const uint32_t v0 = binPos[bin], v1 = binPos[bin + 1];
+    const uint32_t sub = p2_sub(v1 - v0);
+    const uint32_t wb = v0 + wave * sub, we = min(v1, wb + sub);
+    P2Cursor c;
+    P2Regs a, b;
+    const bool busy = wave * sub < v1 - v0;          // uniform per wavefront
+    if (busy) {
+        c.k = waveTile[bin * P2_WAVES + wave];
+        c.delta = tl[c.k].y;
+        c.n1 = tl[c.k + 1];
+        c.n2 = tl[c.k + 2];
+        p2_fetch(a, c, wb, we, lane, tl, prod, lrow);                   // moving before the bin is zeroed
+    }
     for (uint32_t k = threadIdx.x; k < R; k += PB_THREADS) yb[k] = 0.0;
     __syncthreads();
-    const uint32_t wave = threadIdx.x / 64, lane = threadIdx.x % 64;
-    constexpr uint32_t NW = PB_THREADS / 64;
-    const uint32_t d0 = binDesc[bin], nD = binDesc[bin + 1] - d0;
-    const uint2* dsc = desc + d0;
-    for (uint32_t s0 = wave * 64; s0 < nD; s0 += NW * 64) {
-        uint2 mine = make_uint2(0, 0);
-        if (s0 + lane < nD) mine = dsc[s0 + lane];
-        const uint32_t cnt = min(64u, nD - s0);
-        RunRegs a, b;
-        pb_fetch(a, mine, 0, cnt, lane, prod, lrow);
-        for (uint32_t t = 0; t < cnt; t += GROUP) {
-            if (t + GROUP < cnt) pb_fetch(b, mine, t + GROUP, cnt, lane, prod, lrow);
+    if (busy) {
+        // ping-pong between the two register batches (an `a = b` copy would need b's loads to have landed, i.e.
+        // a full wait at the end of every iteration); batches past the end hold nothing but P2_NONE
+        for (uint32_t v = wb; v < we; v += 2 * P2_DEPTH * 64) {
+            p2_fetch(b, c, v + P2_DEPTH * 64, we, lane, tl, prod, lrow);
 #pragma unroll
-            for (int q = 0; q < GROUP; ++q)
-                if (lane < a.ln[q]) atomicAdd(&yb[a.rv[q]], a.pv[q]);
-            a = b;
+            for (int u = 0; u < P2_DEPTH; ++u)
+                if (a.rv[u] != P2_NONE) atomicAdd(&yb[a.rv[u]], a.pv[u]);
+            p2_fetch(a, c, v + 2 * P2_DEPTH * 64, we, lane, tl, prod, lrow);
+#pragma unroll
+            for (int u = 0; u < P2_DEPTH; ++u)
+                if (b.rv[u] != P2_NONE) atomicAdd(&yb[b.rv[u]], b.pv[u]);
         }
     }
     __syncthreads();
@@ -241,30 +326,23 @@ __global__ __launch_bounds__(PB_THREADS) void pb_reduce_kernel(
         if (r0 + k < M) y[r0 + k] = yb[k];
 }
 
-// ---- descriptor-list build ----------------------------------------------------------------------
-// pieces[b*S+s] = number of descriptors of tile (s,b) = ceil(len / PB_SPLIT)
-__global__ __launch_bounds__(256) void pb_pieces_kernel(uint32_t S, uint32_t B, const uint32_t* __restrict__ tileStart,
-                                                        uint32_t* __restrict__ pieces) {
+// where every wavefront of phase 2 starts in the tile list: the last tile of the bin that starts at or before
+// the wavefront's first position
+__global__ __launch_bounds__(256) void pb_wavetile_kernel(uint32_t B, const uint32_t* __restrict__ binPos,
+                                                          const uint32_t* __restrict__ binTile, const uint2* __restrict__ tl,
+                                                          uint32_t* __restrict__ waveTile) {
     const uint64_t i = lin_block() * 256 + threadIdx.x;
-    if (i >= (uint64_t)S * B) return;
-    const uint32_t b = (uint32_t)(i / S), s = (uint32_t)(i % S);
-    const uint64_t t = (uint64_t)s * B + b;
-    pieces[i] = (tileStart[t + 1] - tileStart[t] + PB_SPLIT - 1) / PB_SPLIT;
-}
-// offs = exclusive scan of pieces (bin-major) -> write the descriptors and the per-bin list starts
-__global__ __launch_bounds__(256) void pb_desc_kernel(uint32_t S, uint32_t B, const uint32_t* __restrict__ tileStart,
-                                                      const uint32_t* __restrict__ offs, uint32_t total,
-                                                      uint2* __restrict__ desc, uint32_t* __restrict__ binDesc) {
-    const uint64_t i = lin_block() * 256 + threadIdx.x;
-    if (i >= (uint64_t)S * B) return;
-    const uint32_t b = (uint32_t)(i / S), s = (uint32_t)(i % S);
-    const uint64_t t = (uint64_t)s * B + b;
-    uint32_t a = tileStart[t];
-    const uint32_t e = tileStart[t + 1];
-    uint32_t o = offs[i];
-    if (s == 0) binDesc[b] = o;
-    if (i + 1 == (uint64_t)S * B) binDesc[B] = total;
-    for (; a < e; a += PB_SPLIT) desc[o++] = make_uint2(a, min(PB_SPLIT, e - a));
+    if (i >= (uint64_t)B * P2_WAVES) return;
+    const uint32_t b = (uint32_t)(i / P2_WAVES), wv = (uint32_t)(i % P2_WAVES);
+    const uint32_t v0 = binPos[b], v1 = binPos[b + 1];
+    const uint32_t wb = v0 + wv * p2_sub(v1 - v0);
+    uint32_t lo = binTile[b], hi = binTile[b + 1];  // answer in [lo, hi)
+    if (wb >= v1 || lo >= hi) { waveTile[i] = lo; return; }
+    while (hi - lo > 1) {
+        const uint32_t mid = lo + (hi - lo) / 2;
+        if (tl[mid].x <= wb) lo = mid; else hi = mid;
+    }
+    waveTile[i] = lo;
 }
 
 #define PB_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { fprintf(stderr, "libspmvhip: tiles: %s: %s\n", #expr, hipGetErrorString(e_)); return EXIT_FAILURE; } } while (0)
@@ -280,8 +358,8 @@ struct TempBuf {
 
 void freeTiles(TileFormat* t) {
     if (!t) return;
-    (void)hipFree(t->val); (void)hipFree(t->lcol); (void)hipFree(t->lrow); (void)hipFree(t->desc); (void)hipFree(t->binDesc);
-    (void)hipFree(t->work); (void)hipFree(t->prod);
+    (void)hipFree(t->val); (void)hipFree(t->lcol); (void)hipFree(t->lrow); (void)hipFree(t->tl);
+    (void)hipFree(t->binPos); (void)hipFree(t->waveTile); (void)hipFree(t->work); (void)hipFree(t->prod);
     delete t;
 }
 
@@ -314,7 +392,8 @@ int buildTiles(DevMat* d) {
         tileStart.alloc((nTiles + 2) * 4))
         return fail("temporary allocation");
     if (hipMalloc(&t->val, nnz * 8) || hipMalloc(&t->lcol, nnz * 2) || hipMalloc(&t->lrow, nnz * 2) ||
-        hipMalloc(&t->prod, nnz * 8) || hipMalloc(&t->binDesc, ((size_t)t->B + 1) * 4))
+        hipMalloc(&t->prod, nnz * 8) || hipMalloc(&t->binPos, ((size_t)t->B + 1) * 4) ||
+        hipMalloc(&t->waveTile, (size_t)t->B * P2_WAVES * 4))
         return fail("format allocation");
 
     if (d->irpBytes == 4)
@@ -333,33 +412,44 @@ int buildTiles(DevMat* d) {
     PB_TRY(rocprim::radix_sort_pairs(sortTmp.p, tmpBytes, keys.as<uint16_t>(), keysOut.as<uint16_t>(), idx.as<uint32_t>(),
                                      perm.as<uint32_t>(), (size_t)nnz, 0, bits, (hipStream_t) nullptr));
 
-    hipLaunchKernelGGL(pb_gather_kernel, grid2d((nnz + 255) / 256, 256), dim3(256), 0, nullptr, nnz, perm.as<uint32_t>(),
-                       keysOut.as<uint16_t>(), rowOf.as<uint32_t>(), d->JA, d->AS, t->B, rShift, nTiles, t->val, t->lcol,
-                       t->lrow, tileStart.as<uint32_t>());
+    hipLaunchKernelGGL(pb_bounds_kernel, grid2d((nnz + 255) / 256, 256), dim3(256), 0, nullptr, nnz, perm.as<uint32_t>(),
+                       keysOut.as<uint16_t>(), rowOf.as<uint32_t>(), t->B, rShift, nTiles, tileStart.as<uint32_t>());
     PB_TRY(hipGetLastError());
-    // per-bin descriptor lists: count pieces per tile (bin-major), scan, write
+    // bin-major view: tile lengths (bin-major) -> exclusive scans give every tile's bin-major start and its index
+    // in the list of non-empty tiles
     {
-        TempBuf pieces, offs, scanTmp;
-        if (pieces.alloc(nTiles * 4) || offs.alloc(nTiles * 4)) return fail("descriptor workspace");
-        hipLaunchKernelGGL(pb_pieces_kernel, grid2d((nTiles + 255) / 256, 256), dim3(256), 0, nullptr, t->S, t->B,
-                           tileStart.as<uint32_t>(), pieces.as<uint32_t>());
+        TempBuf lens, flags, bmStart, listIdx, scanTmp, binTile;
+        if (lens.alloc(nTiles * 4) || flags.alloc(nTiles * 4) || bmStart.alloc(nTiles * 4) || listIdx.alloc(nTiles * 4) ||
+            binTile.alloc(((size_t)t->B + 1) * 4))
+            return fail("tile-list workspace");
+        hipLaunchKernelGGL(pb_lens_kernel, grid2d((nTiles + 255) / 256, 256), dim3(256), 0, nullptr, t->S, t->B,
+                           tileStart.as<uint32_t>(), lens.as<uint32_t>(), flags.as<uint32_t>());
         size_t scanBytes = 0;
-        PB_TRY(rocprim::exclusive_scan(nullptr, scanBytes, pieces.as<uint32_t>(), offs.as<uint32_t>(), 0u, (size_t)nTiles,
+        PB_TRY(rocprim::exclusive_scan(nullptr, scanBytes, lens.as<uint32_t>(), bmStart.as<uint32_t>(), 0u, (size_t)nTiles,
                                        rocprim::plus<uint32_t>(), (hipStream_t) nullptr));
         if (scanTmp.alloc(scanBytes)) return fail("scan workspace");
-        PB_TRY(rocprim::exclusive_scan(scanTmp.p, scanBytes, pieces.as<uint32_t>(), offs.as<uint32_t>(), 0u, (size_t)nTiles,
+        PB_TRY(rocprim::exclusive_scan(scanTmp.p, scanBytes, lens.as<uint32_t>(), bmStart.as<uint32_t>(), 0u, (size_t)nTiles,
                                        rocprim::plus<uint32_t>(), (hipStream_t) nullptr));
-        uint32_t lastOff = 0, lastCnt = 0;
-        PB_TRY(hipMemcpy(&lastOff, offs.as<uint32_t>() + nTiles - 1, 4, hipMemcpyDeviceToHost));
-        PB_TRY(hipMemcpy(&lastCnt, pieces.as<uint32_t>() + nTiles - 1, 4, hipMemcpyDeviceToHost));
-        t->nDesc = lastOff + lastCnt;
-        if (hipMalloc(&t->desc, std::max<size_t>(t->nDesc, 1) * sizeof(uint2))) return fail("descriptor allocation");
-        hipLaunchKernelGGL(pb_desc_kernel, grid2d((nTiles + 255) / 256, 256), dim3(256), 0, nullptr, t->S, t->B,
-                           tileStart.as<uint32_t>(), offs.as<uint32_t>(), t->nDesc, t->desc, t->binDesc);
+        PB_TRY(rocprim::exclusive_scan(scanTmp.p, scanBytes, flags.as<uint32_t>(), listIdx.as<uint32_t>(), 0u, (size_t)nTiles,
+                                       rocprim::plus<uint32_t>(), (hipStream_t) nullptr));
+        uint32_t lastIdx = 0, lastFlag = 0;
+        PB_TRY(hipMemcpy(&lastIdx, listIdx.as<uint32_t>() + nTiles - 1, 4, hipMemcpyDeviceToHost));
+        PB_TRY(hipMemcpy(&lastFlag, flags.as<uint32_t>() + nTiles - 1, 4, hipMemcpyDeviceToHost));
+        t->nList = lastIdx + lastFlag;
+        if (hipMalloc(&t->tl, ((size_t)t->nList + TL_PAD) * sizeof(uint2))) return fail("tile-list allocation");
+        hipLaunchKernelGGL(pb_fill_kernel, dim3(1), dim3(256), 0, nullptr, reinterpret_cast<uint32_t*>(t->tl + t->nList), 2 * TL_PAD, 0xFFFFFFFFu);
+        hipLaunchKernelGGL(pb_list_kernel, grid2d((nTiles + 255) / 256, 256), dim3(256), 0, nullptr, t->S, t->B, nnz,
+                           tileStart.as<uint32_t>(), lens.as<uint32_t>(), bmStart.as<uint32_t>(), listIdx.as<uint32_t>(), t->nList,
+                           t->tl, t->binPos, binTile.as<uint32_t>());
+        hipLaunchKernelGGL(pb_gather_kernel, grid2d((nnz + 255) / 256, 256), dim3(256), 0, nullptr, nnz, perm.as<uint32_t>(),
+                           keysOut.as<uint16_t>(), rowOf.as<uint32_t>(), d->JA, d->AS, t->S, t->B, rShift, tileStart.as<uint32_t>(),
+                           bmStart.as<uint32_t>(), t->val, t->lcol, t->lrow);
+        hipLaunchKernelGGL(pb_wavetile_kernel, grid2d(((uint64_t)t->B * P2_WAVES + 255) / 256, 256), dim3(256), 0, nullptr, t->B,
+                           t->binPos, binTile.as<uint32_t>(), t->tl, t->waveTile);
         PB_TRY(hipGetLastError());
         PB_TRY(hipDeviceSynchronize());
     }
-    t->bytes = nnz * 20 + (size_t)t->nDesc * sizeof(uint2) + ((size_t)t->B + 1) * 4;
+    t->bytes = nnz * 20 + ((size_t)t->nList + TL_PAD) * 8 + ((size_t)t->B + 1) * 4 + (size_t)t->B * P2_WAVES * 4;
 
     // phase-1 work list from the slice boundaries (tileStart[s*B])
     std::vector<uint32_t> sliceStart(t->S + 1);
@@ -400,7 +490,7 @@ int enqueueTiles(DevMat* d, const double* x, double* y, hipStream_t stream) {
         hipLaunchKernelGGL(pb_expand_kernel, grid2d(t->nWork, PB_THREADS), dim3(PB_THREADS), PB_C * 8, stream, t->work, t->val,
                            t->lcol, x, d->N, t->prod);
     hipLaunchKernelGGL(pb_reduce_kernel, grid2d(t->B, PB_THREADS), dim3(PB_THREADS), (size_t)8 << t->rShift, stream,
-                       t->rShift, d->M, t->binDesc, t->desc, t->prod, t->lrow, y);
+                       t->rShift, d->M, t->binPos, t->waveTile, t->tl, t->prod, t->lrow, y);
     return hipGetLastError() == hipSuccess ? EXIT_SUCCESS : EXIT_FAILURE;
 }
 
