@@ -157,41 +157,44 @@ __global__ __launch_bounds__(256) void pb_fill_kernel(uint32_t* p, uint64_t n, u
 }
 
 // ---- phase 1 -----------------------------------------------------------------------------------
-// Each lane owns 4 consecutive entries per step (2 x 16-B value loads, one 8-B column load,
-// 2 x 16-B product stores); the work item's range is peeled to a multiple of 4 so every
-// vector access is naturally aligned.  Two steps are kept in flight; the first one is issued
-// before the x slice is staged so the stream is already moving during the LDS fill.
+// Each lane owns 2 consecutive entries per step, consecutive lanes consecutive pairs: every wavefront access is
+// one dense span (1 KiB of values or products, 256 B of columns).  The work item's range is peeled to a
+// multiple of 64 entries at the front, so every span starts on a cache line.  Both matter
+// (scripts/microbench_expand.hip, ns per 1000 entries): 4 entries per lane with two 16-B accesses -- each
+// wavefront instruction touching half of every 32 B -- 3.73 aligned / 3.97 when the range starts 32 B off a
+// line; this layout 3.32 aligned / 3.82 unaligned.  Two batches of P1_DEPTH steps ping-pong in registers (a
+// `cur = nxt` copy would wait for nxt's loads); loads use clamped addresses instead of a bounds branch so the
+// compiler's vmcnt stays exact; the first batch is issued before the x slice is staged so the stream is
+// already moving during the LDS fill.
 typedef double   dbl2 __attribute__((ext_vector_type(2)));
-typedef uint16_t ush4 __attribute__((ext_vector_type(4)));
+typedef uint16_t ush2 __attribute__((ext_vector_type(2)));
 
-constexpr int P1_DEPTH = 4;                         // vector steps in flight per lane (x2: current + next batch)
-struct P1Regs { dbl2 a[P1_DEPTH], b[P1_DEPTH]; ush4 c[P1_DEPTH]; };
+#ifndef SPMV_P1_DEPTH
+#define SPMV_P1_DEPTH 8
+#endif
+constexpr int      P1_DEPTH = SPMV_P1_DEPTH;        // steps per batch
+constexpr uint32_t P1_STEP  = 2 * PB_THREADS;       // entries one workgroup step covers
+struct P1Regs { dbl2 a[P1_DEPTH]; ush2 c[P1_DEPTH]; };
 
+// requires ve - 2 >= first entry of the vector range
 __device__ __forceinline__ void p1_load(P1Regs& r, uint32_t p, uint32_t ve, const double* __restrict__ val,
                                         const uint16_t* __restrict__ lcol) {
-    constexpr uint32_t STEP = 4 * PB_THREADS;
 #pragma unroll
     for (int u = 0; u < P1_DEPTH; ++u) {
-        const uint32_t q = p + u * STEP;
-        if (q < ve) {
-            r.a[u] = __builtin_nontemporal_load((const dbl2*)(val + q));
-            r.b[u] = __builtin_nontemporal_load((const dbl2*)(val + q + 2));
-            r.c[u] = __builtin_nontemporal_load((const ush4*)(lcol + q));
-        } else { r.a[u] = 0; r.b[u] = 0; r.c[u] = 0; }
+        const uint32_t q = min(p + u * P1_STEP, ve - 2u);
+        r.a[u] = __builtin_nontemporal_load((const dbl2*)(val + q));
+        r.c[u] = __builtin_nontemporal_load((const ush2*)(lcol + q));
     }
 }
 
 __device__ __forceinline__ void p1_store(const P1Regs& r, uint32_t p, uint32_t ve, const double* xs, double* __restrict__ prod) {
-    constexpr uint32_t STEP = 4 * PB_THREADS;
 #pragma unroll
     for (int u = 0; u < P1_DEPTH; ++u) {
-        const uint32_t q = p + u * STEP;
+        const uint32_t q = p + u * P1_STEP;
         if (q < ve) {
-            dbl2 r0, r1;
-            r0.x = r.a[u].x * xs[r.c[u].x]; r0.y = r.a[u].y * xs[r.c[u].y];
-            r1.x = r.b[u].x * xs[r.c[u].z]; r1.y = r.b[u].y * xs[r.c[u].w];
-            __builtin_nontemporal_store(r0, (dbl2*)(prod + q));
-            __builtin_nontemporal_store(r1, (dbl2*)(prod + q + 2));
+            dbl2 o;
+            o.x = r.a[u].x * xs[r.c[u].x]; o.y = r.a[u].y * xs[r.c[u].y];
+            __builtin_nontemporal_store(o, (dbl2*)(prod + q));
         }
     }
 }
@@ -202,13 +205,13 @@ __global__ __launch_bounds__(PB_THREADS) void pb_expand_kernel(
     extern __shared__ double xs[];                  // PB_C doubles
     const uint3 w = work[lin_block()];
     const uint32_t begin = w.y, end = w.z;
-    const uint32_t vb = min(end, (begin + 3u) & ~3u);           // first multiple of 4 inside the range
-    const uint32_t ve = vb + ((end - vb) & ~3u);                // end of the whole groups of 4
-    constexpr uint32_t STEP = 4 * PB_THREADS;
+    const uint32_t vb = min(end, (begin + 63u) & ~63u);         // first line-aligned entry inside the range
+    const uint32_t ve = vb + ((end - vb) & ~1u);                // end of the whole pairs
+    const bool vec = ve > vb;                                   // uniform
 
-    uint32_t p = vb + 4 * threadIdx.x;
+    uint32_t p = vb + 2 * threadIdx.x;
     P1Regs cur, nxt;
-    p1_load(cur, p, ve, val, lcol);                 // the stream starts moving before the x slice is staged
+    if (vec) p1_load(cur, p, ve, val, lcol);        // the stream starts moving before the x slice is staged
 
     const uint64_t col0 = (uint64_t)w.x << PB_C_SHIFT;
     {
@@ -223,14 +226,18 @@ __global__ __launch_bounds__(PB_THREADS) void pb_expand_kernel(
     }
     __syncthreads();
 
-    // scalar head and tail (at most 3 entries each)
+    // scalar head (at most 63 entries) and tail (at most 1)
     if (threadIdx.x < vb - begin) { const uint32_t q = begin + threadIdx.x; prod[q] = val[q] * xs[lcol[q]]; }
     if (threadIdx.x < end - ve)   { const uint32_t q = ve + threadIdx.x;    prod[q] = val[q] * xs[lcol[q]]; }
 
-    for (; p < ve; p += P1_DEPTH * STEP) {
-        p1_load(nxt, p + P1_DEPTH * STEP, ve, val, lcol);
-        p1_store(cur, p, ve, xs, prod);
-        cur = nxt;
+    if (vec) {
+        constexpr uint32_t BATCH = P1_DEPTH * P1_STEP;
+        for (; p < ve; p += 2 * BATCH) {
+            p1_load(nxt, p + BATCH, ve, val, lcol);
+            p1_store(cur, p, ve, xs, prod);
+            p1_load(cur, p + 2 * BATCH, ve, val, lcol);
+            p1_store(nxt, p + BATCH, ve, xs, prod);
+        }
     }
 }
 
@@ -284,12 +291,20 @@ __device__ __forceinline__ void p2_fetch(P2Regs& r, P2Cursor& c, uint32_t vbase,
 }
 
 __global__ __launch_bounds__(PB_THREADS) void pb_reduce_kernel(
-    uint32_t rShift, uint64_t M, const uint32_t* __restrict__ binPos, const uint32_t* __restrict__ waveTile,
+    uint32_t rShift, uint32_t nBins, uint64_t M, const uint32_t* __restrict__ binPos, const uint32_t* __restrict__ waveTile,
     const uint2* __restrict__ tl, const double* __restrict__ prod, const uint16_t* __restrict__ lrow,
     double* __restrict__ y) {
     extern __shared__ double yb[];                  // R doubles
     const uint32_t R = 1u << rShift;
+#ifdef SPMV_P2_XCD      // tuning: give every XCD a contiguous range of bins (workgroups are dealt round-robin to the 8 XCDs)
+    const uint64_t i_ = lin_block();
+    const uint32_t per_ = (nBins + 7) / 8;
+    const uint64_t bin = (i_ % 8) * per_ + i_ / 8;
+    if (i_ / 8 >= per_ || bin >= nBins) return;
+#else
     const uint64_t bin = lin_block();
+    if (bin >= nBins) return;
+#endif
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x / 64)), lane = threadIdx.x % 64;
     const uint32_t v0 = binPos[bin], v1 = binPos[bin + 1];
     const uint32_t sub = p2_sub(v1 - v0);
@@ -456,14 +471,19 @@ int buildTiles(DevMat* d) {
     PB_TRY(hipMemcpy2D(sliceStart.data(), 4, tileStart.as<uint32_t>(), (size_t)t->B * 4, 4, t->S + 1, hipMemcpyDeviceToHost));
     std::vector<uint3> work;
     for (uint32_t s = 0; s < t->S; ++s) {
-        // a slice is cut into equal pieces of at most PB_CHUNK entries (multiples of 4 keep the vector loads aligned);
-        // a fixed chunk size + remainder left one short, fill-dominated work item per slice
-        const uint32_t b0 = sliceStart[s], len = sliceStart[s + 1] - b0;
+        // a slice is cut into equal pieces of at most PB_CHUNK entries (a fixed chunk size + remainder left one
+        // short, fill-dominated work item per slice); inner boundaries fall on multiples of 64 entries so that
+        // only a slice's first work item has a scalar head
+        const uint32_t b0 = sliceStart[s], e0 = sliceStart[s + 1], len = e0 - b0;
         if (!len) continue;
         const uint32_t pieces = (len + PB_CHUNK - 1) / PB_CHUNK;
-        const uint32_t piece = ((len + pieces - 1) / pieces + 3) & ~3u;
-        for (uint32_t b = b0; b < b0 + len; b += piece)
-            work.push_back(make_uint3(s, b, std::min<uint32_t>(b + piece, b0 + len)));
+        const uint32_t piece = (len + pieces - 1) / pieces;
+        uint32_t b = b0;
+        for (uint32_t k = 1; k <= pieces && b < e0; ++k) {
+            const uint32_t e = (k == pieces) ? e0 : std::min<uint32_t>(e0, (b0 + k * piece + 63u) & ~63u);
+            if (e > b) work.push_back(make_uint3(s, b, e));
+            b = e;
+        }
     }
     t->nWork = (uint32_t)work.size();
     PB_TRY(hipMalloc(&t->work, std::max<size_t>(work.size(), 1) * sizeof(uint3)));
@@ -489,8 +509,8 @@ int enqueueTiles(DevMat* d, const double* x, double* y, hipStream_t stream) {
     if (t->nWork)
         hipLaunchKernelGGL(pb_expand_kernel, grid2d(t->nWork, PB_THREADS), dim3(PB_THREADS), PB_C * 8, stream, t->work, t->val,
                            t->lcol, x, d->N, t->prod);
-    hipLaunchKernelGGL(pb_reduce_kernel, grid2d(t->B, PB_THREADS), dim3(PB_THREADS), (size_t)8 << t->rShift, stream,
-                       t->rShift, d->M, t->binPos, t->waveTile, t->tl, t->prod, t->lrow, y);
+    hipLaunchKernelGGL(pb_reduce_kernel, grid2d((uint64_t)((t->B + 7) / 8) * 8, PB_THREADS), dim3(PB_THREADS), (size_t)8 << t->rShift, stream,
+                       t->rShift, t->B, d->M, t->binPos, t->waveTile, t->tl, t->prod, t->lrow, y);
     return hipGetLastError() == hipSuccess ? EXIT_SUCCESS : EXIT_FAILURE;
 }
 
