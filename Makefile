@@ -7,7 +7,7 @@ HIPCC    ?= hipcc
 CC        = gcc
 ARCH     ?= gfx950
 PKG       = spmv_openmp_cuda_amd
-HIPSRC    = $(PKG)/csrc/hip/abi.hip $(PKG)/csrc/hip/synth.hip $(PKG)/csrc/hip/shard.hip $(PKG)/csrc/hip/tiles.hip $(PKG)/csrc/hip/sell.hip
+HIPSRC    = $(PKG)/csrc/hip/abi.hip $(PKG)/csrc/hip/synth.hip $(PKG)/csrc/hip/shard.hip $(PKG)/csrc/hip/tiles.hip $(PKG)/csrc/hip/sell.hip $(PKG)/csrc/hip/peer.hip
 HIPHDR    = $(PKG)/csrc/hip/kernels.hpp $(PKG)/csrc/hip/device_mat.hpp include/spmvHip.h include/spmv_types.h
 HIPFLAGS  = --offload-arch=$(ARCH) -O3 -fPIC -shared -std=c++17 -ffp-contract=off -Wall -Wno-unused-function -Iinclude -ldl
 HOSTSRC   = $(wildcard $(PKG)/csrc/host/*.c)

@@ -182,6 +182,40 @@ int spmvHipSpMVSharded(void* shardHandle, const double* hX, int mode, double* hY
                        double* kernelSec, double* gatherSec);
 int spmvHipShardFree(void* shardHandle);
 
+/* ------------------------------------ peer windows: one process per GPU, xGMI */
+/* bench.py's layout (one process per GPU) exchanges y with RCCL by default.  xGMI
+ * is a point-to-point mesh, so the same exchange can also be written as every rank
+ * PUSHING its rows straight into the other ranks' copies of y.  A "window" is a
+ * device allocation other processes of the node can map: its 64-byte handle is
+ * plain data the caller ships to them however it likes (bench.py: torch.distributed
+ * all_gather_object).  New functionality -- the reference is single-GPU. */
+#define SPMV_IPC_HANDLE_BYTES 64
+#define SPMV_MAX_PEERS 15
+int spmvHipWindowCreate(size_t bytes, void** dBase, unsigned char handle[SPMV_IPC_HANDLE_BYTES]);
+int spmvHipWindowFree(void* dBase);
+/* Map a window exported by ANOTHER process whose GPU is device `ownerDev` in this
+ * process' numbering, readable/writable from the current device (peer access is
+ * enabled when the devices differ).  Close before the owner frees it. */
+int spmvHipWindowOpen(const unsigned char handle[SPMV_IPC_HANDLE_BYTES], int ownerDev, void** dPeer);
+int spmvHipWindowClose(void* dPeer);
+/* Copy bytes [offset, offset+bytes) of the own buffer `dSrcBase` to the same offset
+ * of every peer mapping, one copy engine stream per peer, all ordered after what is
+ * enqueued on the library stream so far; returns at once.  spmvHipPeerPushJoin()
+ * makes the library stream wait for every push issued before it. */
+int spmvHipPeerPush(const void* dSrcBase, size_t offset, size_t bytes, int nPeers, void* const* dPeerBases);
+int spmvHipPeerPushJoin(void);
+
+/* The two phases of hipSpMVTilesCSR as separate launches, for callers that overlap
+ * the exchange of y with its production: Expand = phase 1 over the whole matrix;
+ * Reduce = phase 2 for the bins [binBegin, binEnd) -- rows [binBegin*rowsPerBin,
+ * min(binEnd*rowsPerBin, M)) -- stored to dY and, when nExtra > 0, also to the
+ * nExtra further vectors dExtra[k] with the same row indexing (peer mappings: the
+ * all-gather fused into the kernel as direct xGMI stores).  Enqueue-only when
+ * spmvHipSetSync(0).  spmvHipTilesShape builds the format if needed. */
+int spmvHipTilesShape(spmat* dMat, unsigned* nBins, unsigned* rowsPerBin);
+int hipSpMVTilesExpand(spmat* dMat, double* dX);
+int hipSpMVTilesReduce(spmat* dMat, unsigned binBegin, unsigned binEnd, double* dY, int nExtra, double* const* dExtra);
+
 /* ------------------------------------------------- synthetic matrices on device */
 /* Fill JA/AS of a CSR whose row pointers are given (device arrays, device
  * format), for global rows [rowOffset, rowOffset+M): DESIGN.md "Synthetic

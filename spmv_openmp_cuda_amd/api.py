@@ -72,7 +72,15 @@ _sigs = {
     "spmvHipRowBlockCSR": ([C.POINTER(spmat), C.c_ulong, C.c_ulong], C.POINTER(spmat)),
     "spmvHipSynthFillCSR": ([C.c_ulong, C.c_ulong, C.c_ulong, _vp, _i, _vp, _vp, _u64, _u64, C.c_ulong], _i),
     "spmvHipCompactRows": ([_vp, _vp, _vp, _i, C.c_ulong], _i),
+    "spmvHipWindowCreate": ([_sz, C.POINTER(_vp), _vp], _i), "spmvHipWindowFree": ([_vp], _i),
+    "spmvHipWindowOpen": ([_vp, _i, C.POINTER(_vp)], _i), "spmvHipWindowClose": ([_vp], _i),
+    "spmvHipPeerPush": ([_vp, _sz, _sz, _i, _vp], _i), "spmvHipPeerPushJoin": ([], _i),
+    "spmvHipTilesShape": ([C.POINTER(spmat), C.POINTER(C.c_uint), C.POINTER(C.c_uint)], _i),
+    "hipSpMVTilesExpand": ([C.POINTER(spmat), _vp], _i),
+    "hipSpMVTilesReduce": ([C.POINTER(spmat), C.c_uint, C.c_uint, _vp, _i, _vp], _i),
 }
+IPC_HANDLE_BYTES = 64
+MAX_PEERS = 15
 for _name, (_args, _res) in _sigs.items():
     _f = getattr(lib, _name)
     _f.argtypes, _f.restype = _args, _res

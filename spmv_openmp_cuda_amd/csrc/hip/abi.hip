@@ -326,6 +326,8 @@ int hostCall(spmat* mat, double* x, CONFIG* cfg, double* y, int kind, SPMV_HIP_I
 }  // namespace
 
 
+namespace spmvhip { hipStream_t libraryStream() { return S.stream; } }
+
 extern "C" {
 
 // ------------------------------------------------------------------------ lifecycle
@@ -630,6 +632,45 @@ int hipSpMVTilesCSR(spmat* dMat, double* dX, CONFIG cfg, double* dY) {
     Launch L(dim3((unsigned)((d->M + 16383) / 16384)), dim3(1024));
     if (enqueueTiles(d, dX, dY, S.stream)) { ERR("hipSpMVTilesCSR: launch failed"); return EXIT_FAILURE; }
     return L.finish("hipSpMVTilesCSR");
+}
+
+static DevMat* tilesReady(spmat* dMat, const char* who) {
+    DevMat* d = descOf(dMat, who);
+    if (!d) return nullptr;
+    if (d->kind != Kind::CSR || d->M == 0 || d->NZ == 0) { ERR("%s: needs a non-empty CSR handle", who); return nullptr; }
+    if (!d->tiles && buildTiles(d)) return nullptr;
+    return d;
+}
+
+int spmvHipTilesShape(spmat* dMat, unsigned* nBins, unsigned* rowsPerBin) {
+    DevMat* d = tilesReady(dMat, "spmvHipTilesShape");
+    if (!d || !nBins || !rowsPerBin) return EXIT_FAILURE;
+    uint32_t b = 0, r = 0;
+    tilesShape(d, &b, &r);
+    *nBins = b; *rowsPerBin = r;
+    return EXIT_SUCCESS;
+}
+
+int hipSpMVTilesExpand(spmat* dMat, double* dX) {
+    DevMat* d = tilesReady(dMat, "hipSpMVTilesExpand");
+    if (!d) return EXIT_FAILURE;
+    Launch L(dim3(1), dim3(1024));
+    if (enqueueTilesExpand(d, dX, S.stream)) { ERR("hipSpMVTilesExpand: launch failed"); return EXIT_FAILURE; }
+    return L.finish("hipSpMVTilesExpand");
+}
+
+int hipSpMVTilesReduce(spmat* dMat, unsigned binBegin, unsigned binEnd, double* dY, int nExtra, double* const* dExtra) {
+    DevMat* d = tilesReady(dMat, "hipSpMVTilesReduce");
+    if (!d) return EXIT_FAILURE;
+    uint32_t b = 0, r = 0;
+    tilesShape(d, &b, &r);
+    if (binBegin > binEnd || binEnd > b || nExtra < 0 || nExtra > SPMV_MAX_PEERS || (nExtra && !dExtra) || !dY) {
+        ERR("hipSpMVTilesReduce: bins [%u,%u) of %u, %d extra destinations: invalid", binBegin, binEnd, b, nExtra);
+        return EXIT_FAILURE;
+    }
+    Launch L(dim3(binEnd - binBegin ? binEnd - binBegin : 1), dim3(1024));
+    if (enqueueTilesReduce(d, binBegin, binEnd, dY, nExtra, dExtra, S.stream)) { ERR("hipSpMVTilesReduce: launch failed"); return EXIT_FAILURE; }
+    return L.finish("hipSpMVTilesReduce");
 }
 
 int hipSpMVRowsELL(spmat* dMat, double* dX, CONFIG cfg, double* dY) {

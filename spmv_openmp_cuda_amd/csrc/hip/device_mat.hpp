@@ -67,6 +67,10 @@ size_t sellBytes(const DevMat* d);
 int  buildTiles(DevMat* d);                                     // tiles.hip
 void freeTiles(TileFormat* t);
 int  enqueueTiles(DevMat* d, const double* x, double* y, hipStream_t stream);
+int  enqueueTilesExpand(DevMat* d, const double* x, hipStream_t stream);
+int  enqueueTilesReduce(DevMat* d, uint32_t binBegin, uint32_t binEnd, double* y, int nExtra, double* const* extra, hipStream_t stream);
+void tilesShape(const DevMat* d, uint32_t* bins, uint32_t* rowsPerBin);
+hipStream_t libraryStream();                                    // abi.hip: the stream set with spmvHipSetStream
 size_t tilesBytes(const DevMat* d);
 
 // Fold `blocks` workgroups into an (x, y) grid whose x extent keeps

@@ -68,6 +68,8 @@ struct TileFormat {
     size_t    bytes = 0;
 };
 
+struct TileDst { double* p[SPMV_MAX_PEERS]; uint32_t n; };
+
 namespace {
 
 __device__ __forceinline__ uint64_t lin_block() { return (uint64_t)blockIdx.y * gridDim.x + blockIdx.x; }
@@ -290,20 +292,25 @@ __device__ __forceinline__ void p2_fetch(P2Regs& r, P2Cursor& c, uint32_t vbase,
     }
 }
 
+// MULTI: the finished bin of y is also stored to `extra.n` further destinations -- the copies of y that the other
+// ranks of a multi-GPU run hold, mapped into this process (peer windows over xGMI, peer.hip): the all-gather of y
+// is fused into the producing kernel as point-to-point stores, one 512-B run per wavefront instruction.
+template <bool MULTI>
 __global__ __launch_bounds__(PB_THREADS) void pb_reduce_kernel(
-    uint32_t rShift, uint32_t nBins, uint64_t M, const uint32_t* __restrict__ binPos, const uint32_t* __restrict__ waveTile,
+    uint32_t rShift, uint32_t binBegin, uint32_t binEnd, uint64_t M, const uint32_t* __restrict__ binPos, const uint32_t* __restrict__ waveTile,
     const uint2* __restrict__ tl, const double* __restrict__ prod, const uint16_t* __restrict__ lrow,
-    double* __restrict__ y) {
+    double* __restrict__ y, TileDst extra) {
     extern __shared__ double yb[];                  // R doubles
     const uint32_t R = 1u << rShift;
 #ifdef SPMV_P2_XCD      // tuning: give every XCD a contiguous range of bins (workgroups are dealt round-robin to the 8 XCDs)
+    const uint32_t nBins = binEnd - binBegin;
     const uint64_t i_ = lin_block();
     const uint32_t per_ = (nBins + 7) / 8;
-    const uint64_t bin = (i_ % 8) * per_ + i_ / 8;
-    if (i_ / 8 >= per_ || bin >= nBins) return;
+    const uint64_t bin = binBegin + (i_ % 8) * per_ + i_ / 8;
+    if (i_ / 8 >= per_ || bin >= binEnd) return;
 #else
-    const uint64_t bin = lin_block();
-    if (bin >= nBins) return;
+    const uint64_t bin = binBegin + lin_block();
+    if (bin >= binEnd) return;
 #endif
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x / 64)), lane = threadIdx.x % 64;
     const uint32_t v0 = binPos[bin], v1 = binPos[bin + 1];
@@ -339,6 +346,15 @@ __global__ __launch_bounds__(PB_THREADS) void pb_reduce_kernel(
     const uint64_t r0 = bin << rShift;
     for (uint32_t k = threadIdx.x; k < R; k += PB_THREADS)
         if (r0 + k < M) y[r0 + k] = yb[k];
+    if (MULTI) {
+        // destination-major (long contiguous runs per link); workgroups start at different destinations so that
+        // all links carry traffic all the time
+        for (uint32_t i = 0; i < extra.n; ++i) {
+            double* __restrict__ dst = extra.p[(i + (uint32_t)bin) % extra.n];
+            for (uint32_t k = threadIdx.x; k < R; k += PB_THREADS)
+                if (r0 + k < M) dst[r0 + k] = yb[k];
+        }
+    }
 }
 
 // where every wavefront of phase 2 starts in the tile list: the last tile of the bin that starts at or before
@@ -493,7 +509,8 @@ int buildTiles(DevMat* d) {
     static bool attrSet = false;
     if (!attrSet) {
         PB_TRY(hipFuncSetAttribute((const void*)pb_expand_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, PB_C * 8));
-        PB_TRY(hipFuncSetAttribute((const void*)pb_reduce_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (1 << PB_R_MAX_SHIFT) * 8));
+        PB_TRY(hipFuncSetAttribute((const void*)pb_reduce_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (1 << PB_R_MAX_SHIFT) * 8));
+        PB_TRY(hipFuncSetAttribute((const void*)pb_reduce_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (1 << PB_R_MAX_SHIFT) * 8));
         attrSet = true;
     }
     d->tiles = t;
@@ -502,16 +519,46 @@ int buildTiles(DevMat* d) {
 
 size_t tilesBytes(const DevMat* d) { return d->tiles ? d->tiles->bytes : 0; }
 
-// enqueue both phases on `stream`
-int enqueueTiles(DevMat* d, const double* x, double* y, hipStream_t stream) {
+void tilesShape(const DevMat* d, uint32_t* bins, uint32_t* rowsPerBin) {
+    *bins = d->tiles ? d->tiles->B : 0;
+    *rowsPerBin = d->tiles ? 1u << d->tiles->rShift : 0;
+}
+
+// phase 1 on `stream`: products of the whole matrix into the format's workspace
+int enqueueTilesExpand(DevMat* d, const double* x, hipStream_t stream) {
     TileFormat* t = d->tiles;
     if (!t) return EXIT_FAILURE;
     if (t->nWork)
         hipLaunchKernelGGL(pb_expand_kernel, grid2d(t->nWork, PB_THREADS), dim3(PB_THREADS), PB_C * 8, stream, t->work, t->val,
                            t->lcol, x, d->N, t->prod);
-    hipLaunchKernelGGL(pb_reduce_kernel, grid2d((uint64_t)((t->B + 7) / 8) * 8, PB_THREADS), dim3(PB_THREADS), (size_t)8 << t->rShift, stream,
-                       t->rShift, t->B, d->M, t->binPos, t->waveTile, t->tl, t->prod, t->lrow, y);
     return hipGetLastError() == hipSuccess ? EXIT_SUCCESS : EXIT_FAILURE;
+}
+
+// phase 2 on `stream` for the bins [binBegin, binEnd): rows [binBegin * R, min(binEnd * R, M)) of y, stored to y and
+// to the nExtra further destinations (same row indexing)
+int enqueueTilesReduce(DevMat* d, uint32_t binBegin, uint32_t binEnd, double* y, int nExtra, double* const* extra, hipStream_t stream) {
+    TileFormat* t = d->tiles;
+    if (!t || binBegin > binEnd || binEnd > t->B || nExtra < 0 || nExtra > SPMV_MAX_PEERS) return EXIT_FAILURE;
+    if (binBegin == binEnd) return EXIT_SUCCESS;
+    const dim3 grid = grid2d((uint64_t)((binEnd - binBegin + 7) / 8) * 8, PB_THREADS);
+    TileDst dst{};
+    dst.n = (uint32_t)nExtra;
+    for (int i = 0; i < nExtra; ++i) dst.p[i] = extra[i];
+    if (nExtra)
+        hipLaunchKernelGGL(pb_reduce_kernel<true>, grid, dim3(PB_THREADS), (size_t)8 << t->rShift, stream,
+                           t->rShift, binBegin, binEnd, d->M, t->binPos, t->waveTile, t->tl, t->prod, t->lrow, y, dst);
+    else
+        hipLaunchKernelGGL(pb_reduce_kernel<false>, grid, dim3(PB_THREADS), (size_t)8 << t->rShift, stream,
+                           t->rShift, binBegin, binEnd, d->M, t->binPos, t->waveTile, t->tl, t->prod, t->lrow, y, dst);
+    return hipGetLastError() == hipSuccess ? EXIT_SUCCESS : EXIT_FAILURE;
+}
+
+// enqueue both phases on `stream`
+int enqueueTiles(DevMat* d, const double* x, double* y, hipStream_t stream) {
+    TileFormat* t = d->tiles;
+    if (!t) return EXIT_FAILURE;
+    if (enqueueTilesExpand(d, x, stream)) return EXIT_FAILURE;
+    return enqueueTilesReduce(d, 0, t->B, y, 0, nullptr, stream);
 }
 
 }  // namespace spmvhip

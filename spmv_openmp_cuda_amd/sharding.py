@@ -121,3 +121,156 @@ def step(plan, dist, bufs, compute_group):
         w.wait()
         bufs.compact(g)
     return bufs.y
+
+
+# ---------------------------------------------------------------------------------------------------------
+# Push exchange over peer windows (include/spmvHip.h "peer windows"): xGMI is a point-to-point mesh, so the
+# all-gather of y can also be written as every rank storing its rows straight into the other ranks' vectors --
+# with the copy engines behind every finished piece of y (`PeerExchange.push`) or from inside the producing
+# kernel (`PeerExchange.extra_pointers` handed to hipSpMVTilesReduce).  No padding, no compaction: every rank's
+# y is one window of M doubles and rank r owns rows plan.rows(r) of ALL of them.
+class _RawDeviceArray:
+    """a raw device pointer as something torch.as_tensor() understands"""
+
+    def __init__(self, ptr, n, typestr="<f8"):
+        self.__cuda_array_interface__ = {"shape": (int(n),), "typestr": typestr, "data": (int(ptr), False), "version": 2}
+
+
+class PeerExchange:
+    """Collective constructor (every rank of `dist`'s default group calls it): creates this rank's window of
+    `n` doubles, ships the handles with all_gather_object and maps the others' windows.  `ok` is the same on
+    every rank; when False nothing is left allocated and the caller stays on the RCCL path."""
+
+    def __init__(self, api, dist, torch, rank, world, device_index, n):
+        import ctypes as C
+        self.api, self.dist, self.torch = api, dist, torch
+        self.rank, self.world, self.n = rank, world, int(n)
+        self.base = None
+        self.peer_base = {}
+        self.ok = False
+        self.why = ""
+        handle = (C.c_ubyte * api.IPC_HANDLE_BYTES)()
+        base = C.c_void_p()
+        good = world - 1 <= api.MAX_PEERS and api.lib.spmvHipWindowCreate(self.n * 8, C.byref(base), handle) == 0
+        if good:
+            self.base = base
+        mine = (bytes(handle), int(device_index), bool(good))
+        everyone = [None] * world
+        dist.all_gather_object(everyone, mine)
+        if all(e[2] for e in everyone):
+            for p, (h, dev, _) in enumerate(everyone):
+                if p == rank:
+                    continue
+                buf = (C.c_ubyte * api.IPC_HANDLE_BYTES).from_buffer_copy(h)
+                ptr = C.c_void_p()
+                if api.lib.spmvHipWindowOpen(buf, dev, C.byref(ptr)) != 0:
+                    good = False
+                    self.why = f"rank {rank}: cannot map the window of rank {p} (device {dev})"
+                    break
+                self.peer_base[p] = ptr
+        else:
+            good = False
+            self.why = "window allocation failed on some rank"
+        verdict = [None] * world
+        dist.all_gather_object(verdict, (bool(good), self.why))
+        self.ok = all(v[0] for v in verdict)
+        if not self.ok:
+            self.why = "; ".join(v[1] for v in verdict if v[1]) or self.why
+            self.close()
+            return
+        # peers in ring order starting behind this rank: at any moment the ranks write to different targets
+        self.order = [(rank + k) % world for k in range(1, world)]
+        self._peer_array = (C.c_void_p * max(len(self.order), 1))(*[self.peer_base[p].value for p in self.order])
+        self.y = torch.as_tensor(_RawDeviceArray(self.base.value, self.n), device="cuda")
+        self._flag = torch.zeros(1, dtype=torch.int32, device="cuda")
+
+    def extra_pointers(self, row0):
+        """(count, array of double*) -- the peers' y vectors offset to this rank's first row, for the fused store"""
+        import ctypes as C
+        arr = (C.c_void_p * max(len(self.order), 1))(*[self.peer_base[p].value + 8 * int(row0) for p in self.order])
+        return len(self.order), arr
+
+    def push(self, row0, row1):
+        """rows [row0, row1) of the own y to every peer, behind what is enqueued on the library stream"""
+        if row1 > row0 and self.api.lib.spmvHipPeerPush(self.base, 8 * int(row0), 8 * int(row1 - row0), len(self.order), self._peer_array):
+            raise RuntimeError("spmvHipPeerPush failed")
+
+    def finish(self, barrier=None):
+        """own pushes done (in stream order), then a node-wide barrier: afterwards every rank's y is complete"""
+        if self.api.lib.spmvHipPeerPushJoin():
+            raise RuntimeError("spmvHipPeerPushJoin failed")
+        if barrier is not None:
+            barrier()
+        else:
+            self.dist.all_reduce(self._flag)         # RCCL, in stream order: returns on a rank only after every rank entered it
+
+    def close(self):
+        self.y = None
+        for ptr in self.peer_base.values():
+            self.api.lib.spmvHipWindowClose(ptr)
+        self.peer_base = {}
+        try:
+            self.dist.barrier()                          # nobody frees a window that is still mapped elsewhere
+        except Exception:
+            pass
+        if self.base is not None:
+            self.api.lib.spmvHipWindowFree(self.base)
+            self.base = None
+
+
+def bin_ranges(n_bins, pieces):
+    """cut [0, n_bins) into `pieces` nearly equal consecutive ranges (empty ones dropped)"""
+    pieces = max(1, min(int(pieces), int(n_bins)))
+    cuts = [(n_bins * k) // pieces for k in range(pieces + 1)]
+    return [(cuts[k], cuts[k + 1]) for k in range(pieces) if cuts[k + 1] > cuts[k]]
+
+
+class PushSpMV:
+    """This rank's rows of y = A.x written into its window and delivered to the peers.
+    mode "push":  kernel pieces -> copy-engine pushes behind each piece (tiles launcher: phase 1 once, phase 2 cut
+                  into `pieces` bin ranges so that the push of one range travels under the reduction of the next;
+                  other launchers: one piece);
+    mode "fused": hipSpMVTilesReduce stores every finished bin to all the peers itself (tiles launcher only)."""
+
+    def __init__(self, api, px, dm, row0, launcher, x_ptr, mode="push", pieces=1, barrier=None):
+        import ctypes as C
+        self.api, self.px, self.dm, self.row0, self.launcher = api, px, dm, int(row0), launcher
+        self.x_ptr, self.mode, self.barrier = x_ptr, mode, barrier
+        self.cfg = api.CONFIG()
+        self.rows = int(dm.rows)
+        self.y_own = C.c_void_p(px.base.value + 8 * self.row0)
+        self.tiles = launcher == "hipSpMVTilesCSR" and self.rows > 0 and int(dm.nnz) > 0
+        if mode == "fused" and not self.tiles:
+            raise ValueError("the fused exchange exists for hipSpMVTilesCSR only")
+        if self.tiles:
+            nb, rpb = C.c_uint(), C.c_uint()
+            if api.lib.spmvHipTilesShape(C.byref(dm.handle), C.byref(nb), C.byref(rpb)):
+                raise RuntimeError("spmvHipTilesShape failed")
+            self.rpb = int(rpb.value)
+            self.ranges = bin_ranges(int(nb.value), pieces if mode == "push" else 1)
+            self.n_extra, self.extra = px.extra_pointers(self.row0)
+        self.pieces = len(self.ranges) if self.tiles else 1
+
+    def step(self, ev=None):
+        import ctypes as C
+        api, lib, h = self.api, self.api.lib, C.byref(self.dm.handle)
+        if ev:
+            lib.spmvHipEventRecord(ev[0])
+        if self.tiles:
+            rc = lib.hipSpMVTilesExpand(h, self.x_ptr)
+            if self.mode == "fused":
+                b0, b1 = self.ranges[0][0], self.ranges[-1][1]
+                rc = rc or lib.hipSpMVTilesReduce(h, b0, b1, self.y_own, self.n_extra, self.extra)
+            else:
+                for b0, b1 in self.ranges:
+                    rc = rc or lib.hipSpMVTilesReduce(h, b0, b1, self.y_own, 0, None)
+                    self.px.push(self.row0 + b0 * self.rpb, self.row0 + min(b1 * self.rpb, self.rows))
+        else:
+            rc = api.SPMV_LAUNCHERS[self.launcher](h, self.x_ptr, self.cfg, self.y_own) if self.rows else 0
+            self.px.push(self.row0, self.row0 + self.rows)
+        if ev:
+            lib.spmvHipEventRecord(ev[1])
+        if rc:
+            raise RuntimeError(self.launcher + " failed")
+        self.px.finish(self.barrier)
+        return self.px.y

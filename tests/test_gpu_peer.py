@@ -1,0 +1,132 @@
+"""Push exchange over peer windows (include/spmvHip.h "peer windows", sharding.PeerExchange / PushSpMV) on the
+one-GPU box: `world` processes share GPU 0, map each other's y windows over device IPC and deliver their rows
+with (a) copy-engine pushes behind every piece of y and (b) the stores fused into hipSpMVTilesReduce.  The
+control plane is gloo here (RCCL refuses two ranks on one device); on the 8-GPU node bench.py runs the same
+classes with RCCL as the control plane and xGMI under the copies.  Every rank must end with the full y:
+bit-identical on all ranks, equal to the serial oracle (bitwise for the serial-order launcher)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, out_dir):
+    import ctypes as C
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from conftest import Oracle
+    from spmv_openmp_cuda_amd import api, sharding, synth
+    api.spmvHipInit(0)
+    api.lib.spmvHipSetStream(C.c_void_p(torch.cuda.current_stream().cuda_stream))
+    api.lib.spmvHipSetSync(0)
+    oracle = Oracle()
+    w = synth.Workload("p", 300_007, 6_000_000, "powerlaw", 20000, 9)
+    lens = synth.row_lengths(w)
+    irp = synth.prefix(lens)
+    x_host = synth.make_x(w.N, w.cfg)
+    x = torch.from_numpy(x_host).cuda()
+    ja_all, as_all = oracle.synth_fill(w.N, 0, irp, synth.SEED_STRUCT + w.cfg, synth.SEED_VAL + w.cfg, 0)
+    y_ref = oracle.csr_serial_dev(irp.astype(np.uint32), ja_all, as_all, x_host)
+    scale = np.add.reduceat(np.abs(as_all * x_host[ja_all]), irp[:-1].astype(np.int64))
+
+    def host_barrier():
+        torch.cuda.synchronize()
+        dist.barrier()
+
+    plan = sharding.make_plan(irp, world, 1)
+    r0, r1 = plan.rows(rank)
+    dm = synth.device_csr(w, irp, r0, r1)
+    px = sharding.PeerExchange(api, dist, torch, rank, world, 0, w.N)
+    verdict = []
+    ok = px.ok
+    if not ok:
+        verdict.append("setup: " + px.why)
+    cases = [("hipSpMVRowsCSR", "push", 1, True), ("hipSpMVWarpPerRowCSR", "push", 1, False),
+             ("hipSpMVTilesCSR", "push", 1, False), ("hipSpMVTilesCSR", "push", 3, False),
+             ("hipSpMVTilesCSR", "fused", 1, False)]
+    for launcher, mode, pieces, exact in (cases if ok else []):
+        run = sharding.PushSpMV(api, px, dm, r0, launcher, x.data_ptr(), mode, pieces, barrier=host_barrier)
+        px.y.fill_(float("nan"))
+        host_barrier()
+        for _ in range(2):                               # two steps: the windows are re-used
+            y = run.step()
+        host_barrier()
+        yh = y.cpu().numpy()
+        good = not np.isnan(yh).any()
+        good = good and (np.array_equal(yh, y_ref) if exact else bool(np.all(np.abs(yh - y_ref) <= 1e-13 * scale + 1e-300)))
+        sums = [None] * world
+        dist.all_gather_object(sums, yh.tobytes() if w.N < 1_000_000 else float(yh.sum()))
+        good = good and all(s == sums[0] for s in sums)  # every rank holds the same bytes
+        if not good:
+            verdict.append(f"{launcher}/{mode}/{pieces}: mismatch (max |dy| {np.nanmax(np.abs(yh - y_ref)):.3e}, "
+                           f"nan {int(np.isnan(yh).sum())})")
+        ok = ok and good
+        host_barrier()
+    dm.free()
+    px.close()
+    with open(os.path.join(out_dir, f"rank{rank}.txt"), "w") as f:
+        f.write("ok" if ok else "FAILED: " + "; ".join(verdict))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_push_exchange_shared_gpu(tmp_path, world):
+    port = _free_port()
+    mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    for r in range(world):
+        assert (tmp_path / f"rank{r}.txt").read_text() == "ok"
+
+
+def test_tiles_reduce_bin_ranges_single_process():
+    """phase 2 cut into bin ranges == the one-launch result (same kernel, same order inside a bin up to atomics)"""
+    import ctypes as C
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from conftest import Oracle
+    from spmv_openmp_cuda_amd import api, synth
+    api.spmvHipInit(0)
+    api.lib.spmvHipSetStream(None)
+    api.lib.spmvHipSetSync(1)
+    oracle = Oracle()
+    w = synth.Workload("p", 200_003, 4_000_000, "powerlaw", 20000, 9)
+    lens = synth.row_lengths(w)
+    irp = synth.prefix(lens)
+    x_host = synth.make_x(w.N, w.cfg)
+    dm = synth.device_csr(w, irp, 0, w.N)
+    dx = api.DeviceVector(w.N).up(x_host)
+    dy = api.DeviceVector(w.N)
+    dy.poison()
+    nb, rpb = C.c_uint(), C.c_uint()
+    assert api.lib.spmvHipTilesShape(C.byref(dm.handle), C.byref(nb), C.byref(rpb)) == 0
+    assert nb.value * rpb.value >= w.N > (nb.value - 1) * rpb.value
+    assert api.lib.hipSpMVTilesExpand(C.byref(dm.handle), dx.ptr) == 0
+    from spmv_openmp_cuda_amd.sharding import bin_ranges
+    for b0, b1 in reversed(bin_ranges(nb.value, 5)):     # any order of the ranges
+        assert api.lib.hipSpMVTilesReduce(C.byref(dm.handle), b0, b1, dy.ptr, 0, None) == 0
+    y = dy.down()
+    ja, as_ = oracle.synth_fill(w.N, 0, irp, synth.SEED_STRUCT + w.cfg, synth.SEED_VAL + w.cfg, 0)
+    y_ref = oracle.csr_serial_dev(irp.astype(np.uint32), ja, as_, x_host)
+    scale = np.add.reduceat(np.abs(as_ * x_host[ja]), irp[:-1].astype(np.int64))
+    assert not np.isnan(y).any()
+    assert np.all(np.abs(y - y_ref) <= 1e-13 * scale + 1e-300)
+    # invalid ranges fail loudly
+    assert api.lib.hipSpMVTilesReduce(C.byref(dm.handle), 2, 1, dy.ptr, 0, None) == 1
+    assert api.lib.hipSpMVTilesReduce(C.byref(dm.handle), 0, nb.value + 1, dy.ptr, 0, None) == 1
+    dm.free()
