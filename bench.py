@@ -53,6 +53,10 @@ def parse():
     p.add_argument("--cpu-sample-nnz", type=int, default=100_000_000)
     p.add_argument("--groups", type=int, default=0,
                    help="row groups per rank for kernel/all-gather overlap at N > 1 (0 = measure 1/2[/4] and keep the fastest)")
+    p.add_argument("--exchange", default="auto", choices=["auto", "rccl", "push", "fused"],
+                   help="how y reaches the other ranks at N > 1: RCCL all-gather, copy-engine pushes into peer windows, or "
+                        "stores fused into phase 2 of the two-phase kernel (auto = measure all, keep the fastest)")
+    p.add_argument("--pieces", type=int, default=0, help="pieces of y per rank for --exchange push (0 = measure 1/2/4/8)")
     p.add_argument("--force-dist", action="store_true",
                    help="run the multi-rank code path (process group, all-gather) even with --gpus 1; for rehearsal")
     return p.parse_args()
@@ -411,19 +415,24 @@ def main():
     x = torch.from_numpy(x_host).cuda()
     cfg = api.CONFIG()
 
-    class Setup:
-        """this rank's `groups` row groups as device matrices + gather buffers"""
-        def __init__(self, groups):
-            self.groups = groups
+    class RcclExchange:
+        """this rank's `groups` row groups as device matrices + gather buffers; kernel(g) -> async RCCL all-gather(g)"""
+        def __init__(self, groups, first=None):
+            self.groups = self.events = groups
+            self.name = f"rccl-g{groups}"
             self.plan = sharding.make_plan(irp, world, groups)
-            self.dms = [synth.device_csr(w, irp, *self.plan.block(rank, g)) for g in range(groups)]
+            self.dms = [first] if (first is not None and groups == 1) else \
+                [synth.device_csr(w, irp, *self.plan.block(rank, g)) for g in range(groups)]
+            self.owns = not (first is not None and groups == 1)
             self.bufs = sharding.GatherBuffers(self.plan, rank, torch, "cuda")
+            self.y = self.bufs.y
+            self.desc = (f"{world} ranks x {groups} nnz-balanced row groups; per group: kernel then async RCCL "
+                         f"all-gather(y) overlapping the next group" + ("" if self.plan.equal_blocks else "; padded blocks + compaction"))
 
-        def warm(self, fn):                         # builds the per-group formats outside any timed region
-            for g, dm in enumerate(self.dms):
-                if fn(C.byref(dm.handle), x.data_ptr(), cfg, self.bufs.slot[g].data_ptr()):
-                    raise RuntimeError("launcher failed")
-            torch.cuda.synchronize()
+        def poison(self):
+            for b in self.bufs.ypad:
+                b.fill_(float("nan"))
+            self.bufs.y.fill_(float("nan"))
 
         def step(self, fn, ev=None):
             def compute_group(g, slot):
@@ -434,36 +443,91 @@ def main():
                     api.lib.spmvHipEventRecord(ev[g][1])
                 if rc:
                     raise RuntimeError("launcher failed")
-            # kernel(g) -> async RCCL all-gather(g) over xGMI (overlaps group g+1), then compaction
             return sharding.step(self.plan, dist, self.bufs, compute_group)
 
         def free(self):
-            for dm in self.dms:
-                dm.free()
-            self.dms, self.bufs = [], None
+            if self.owns:
+                for dm in self.dms:
+                    dm.free()
+            self.dms, self.bufs, self.y = [], None, None
 
-    # every rank must run the same kernel: rank 0 decides (on its first group of the 1-group setup)
-    setup = Setup(1)
-    launcher, tried = pick_launcher(api, torch, setup.dms[0], x.data_ptr(), setup.bufs.slot[0].data_ptr(), args.launcher)
+    class PushExchange:
+        """y lives in a peer window; this rank's rows are delivered to the other ranks' windows by copy-engine pushes
+        behind each piece of y ("push-pQ") or by stores fused into phase 2 of the two-phase kernel ("fused")"""
+        def __init__(self, px, dm, mode, pieces):
+            self.events = 1
+            self.plan = base_plan
+            self.run = sharding.PushSpMV(api, px, dm, base_plan.rows(rank)[0], launcher, x.data_ptr(), mode, pieces)
+            self.name = "fused" if mode == "fused" else f"push-p{self.run.pieces}"
+            self.y = px.y
+            self.groups = 1
+            self.desc = (f"{world} ranks, one nnz-balanced row block each, y in peer windows (device IPC over xGMI): " +
+                         ("phase 2 stores every finished bin of y to all ranks itself" if mode == "fused" else
+                          f"{self.run.pieces} piece(s) of y, each pushed to all ranks by the copy engines while the next is reduced") +
+                         "; step ends with a 4-byte RCCL all-reduce as barrier")
+
+        def poison(self):
+            self.y.fill_(float("nan"))
+
+        def step(self, fn, ev=None):
+            return self.run.step(ev[0] if ev else None)
+
+        def free(self):
+            self.run, self.y = None, None
+
+    # every rank must run the same kernel: rank 0 decides (on its block of the 1-group plan)
+    base_plan = sharding.make_plan(irp, world, 1)
+    base_dm = synth.device_csr(w, irp, *base_plan.block(rank, 0))
+    first = RcclExchange(1, base_dm)
+    launcher, tried = pick_launcher(api, torch, base_dm, x.data_ptr(), first.bufs.slot[0].data_ptr(), args.launcher)
     choice = torch.tensor([AUTO_CANDIDATES.index(launcher) if launcher in AUTO_CANDIDATES else -1], device="cuda")
     dist.broadcast(choice, 0)
     if int(choice) >= 0:
         launcher = AUTO_CANDIDATES[int(choice)]
     fn = api.SPMV_LAUNCHERS[launcher]
 
-    # row groups per rank: more groups overlap more of the gather but make every group's kernels less
-    # efficient; which wins depends on the xGMI gather rate, so it is MEASURED: whole steps (kernels +
-    # gather + compaction), slowest rank, 3 steps per candidate
-    group_ms = {}
-    if args.groups > 0:
-        candidates = [args.groups]
-    else:
-        candidates = [1, 2, 4] if world == 2 else [1, 2]
-    best = None
-    for G in candidates:
-        cand = setup if G == 1 else Setup(G)
-        cand.warm(fn)
+    # How y is exchanged is MEASURED, not assumed (no multi-GPU node at development time): RCCL all-gather with 1/2[/4]
+    # row groups per rank (more groups overlap more of the gather but make every group's kernels less efficient), the
+    # push exchange over peer windows with 1..8 pieces, and the fused store.  Whole steps, slowest rank, 3 steps each;
+    # a candidate whose y differs from the first candidate's is dropped.
+    px = None
+    if args.exchange in ("auto", "push", "fused"):
+        px = sharding.PeerExchange(api, dist, torch, rank, world, local, w.N)
+        if not px.ok:
+            log("peer windows unavailable, RCCL only:", px.why)
+            px = None
+    def candidates():
+        if args.exchange in ("auto", "rccl"):
+            for G in ([args.groups] if args.groups > 0 else ([1, 2, 4] if world == 2 else [1, 2])):
+                yield (lambda G=G: first if G == 1 else RcclExchange(G))
+        if px is not None and args.exchange in ("auto", "push"):
+            for q in ([args.pieces] if args.pieces > 0 else ([1, 2, 4, 8] if launcher == "hipSpMVTilesCSR" else [1])):
+                yield (lambda q=q: PushExchange(px, base_dm, "push", q))
+        # the fused store is tried only after a copy-engine push through the same mappings delivered a correct y
+        if px is not None and args.exchange in ("auto", "fused") and launcher == "hipSpMVTilesCSR" and \
+                (args.exchange == "fused" or any(k.startswith("push") for k in exchange_ms)):
+            yield (lambda: PushExchange(px, base_dm, "fused", 1))
+    exchange_ms, rejected = {}, {}
+    best, ref_sum = None, None
+    for make in candidates():
+        cand = make()
+        if cand.name in exchange_ms or cand.name in rejected:      # e.g. fewer pieces than asked for
+            continue
+        cand.poison()
         cand.step(fn)
+        torch.cuda.synchronize()
+        y_c = cand.y
+        sums = torch.stack([y_c.abs().sum(), torch.isnan(y_c).sum().to(torch.float64)])
+        if ref_sum is None:
+            ref_sum = sums[0].clone()
+        good = torch.tensor([1.0 if (float(sums[1]) == 0 and abs(float(sums[0] - ref_sum)) <= 1e-9 * float(ref_sum)) else 0.0],
+                            dtype=torch.float64, device="cuda")
+        dist.all_reduce(good, op=dist.ReduceOp.MIN)
+        if float(good[0]) == 0.0:
+            rejected[cand.name] = "y incomplete or different on some rank"
+            if cand is not first:
+                cand.free()
+            continue
         dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -472,18 +536,19 @@ def main():
         torch.cuda.synchronize()
         tt = torch.tensor([(time.perf_counter() - t0) / 3 * 1e3], dtype=torch.float64, device="cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        group_ms[G] = float(tt[0])
-        if best is None or group_ms[G] < group_ms[best.groups]:
-            if best is not None:
+        exchange_ms[cand.name] = float(tt[0])
+        if best is None or exchange_ms[cand.name] < exchange_ms[best.name]:
+            if best is not None and best is not first:
                 best.free()
             best = cand
-        else:
+        elif cand is not first:
             cand.free()
         torch.cuda.empty_cache()
-    if setup is not best and setup.dms:
-        setup.free()
+    if best is None:
+        raise SystemExit(f"no exchange candidate produced a complete y: {rejected}")
     setup = best
-    groups, plan, bufs, dms = setup.groups, setup.plan, setup.bufs, setup.dms
+    log("exchange candidates (ms/step, slowest rank):", exchange_ms, "rejected:", rejected, "->", setup.name)
+    groups, plan = setup.events, setup.plan
     r0, r1 = plan.rows(rank)
     nnz_local = int(irp[r1] - irp[r0])
     evs = [[(C.c_void_p(), C.c_void_p()) for _ in range(groups)] for _ in range(steps)]
@@ -495,9 +560,10 @@ def main():
     def step(ev):
         setup.step(fn, ev)
 
+    setup.poison()
     wall = time_kernel_loop(api, torch, dist, world, step, steps, warmup, evs)
     kms = [sum(kernel_ms(api, per_step)) for per_step in evs]
-    y = bufs.y
+    y = setup.y
     t = torch.tensor([wall, sum(kms) / len(kms)], dtype=torch.float64, device="cuda")
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     wall_max, kernel_ms_max = float(t[0]), float(t[1])
@@ -516,10 +582,8 @@ def main():
             "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": wall_max / steps * 1e3,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": info["workload"], **{k: v for k, v in info.items() if k != "workload"},
-                       "kernel": launcher, "auto_candidates_ms": tried, "row_groups_step_ms": group_ms,
-                       "parallelism": f"{world} ranks x {groups} nnz-balanced row groups; per group: kernel then async "
-                                      f"RCCL all-gather(y) overlapping the next group" +
-                                      ("" if plan.equal_blocks else "; padded blocks + compaction")},
+                       "kernel": launcher, "auto_candidates_ms": tried, "exchange": setup.name,
+                       "exchange_step_ms": exchange_ms, "exchange_rejected": rejected, "parallelism": setup.desc},
             "hbm_gbps": bytes_alg_total / (wall_max / steps) * 1e-9,
             "hbm_roofline_frac": bytes_alg_total / (wall_max / steps) / (HBM_PEAK * world),
             "roofline": {"bound": "hbm", "achieved": bytes_alg_local / k_avg * 1e-9, "peak": HBM_PEAK * 1e-9,
@@ -534,8 +598,12 @@ def main():
         }
         emit(line)
     dist.barrier()
-    for dm in dms:
-        dm.free()
+    if setup is not first:
+        setup.free()
+    first.free()
+    base_dm.free()
+    if px is not None:
+        px.close()
     api.spmvHipFinalize()
     dist.destroy_process_group()
 

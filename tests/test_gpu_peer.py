@@ -62,7 +62,7 @@ def _worker(rank, world, port, out_dir):
              ("hipSpMVTilesCSR", "push", 1, False), ("hipSpMVTilesCSR", "push", 3, False),
              ("hipSpMVTilesCSR", "fused", 1, False)]
     for launcher, mode, pieces, exact in (cases if ok else []):
-        run = sharding.PushSpMV(api, px, dm, r0, launcher, x.data_ptr(), mode, pieces, barrier=host_barrier)
+        run = sharding.PushSpMV(api, px, dm, r0, launcher, x.data_ptr(), mode, pieces, barrier=host_barrier, unit=4)
         px.y.fill_(float("nan"))
         host_barrier()
         for _ in range(2):                               # two steps: the windows are re-used

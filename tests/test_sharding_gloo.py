@@ -68,3 +68,16 @@ def test_sharded_spmv_gloo(tmp_path, world, equal_rows, groups):
     mp.spawn(_worker, args=(world, port, equal_rows, groups, str(tmp_path)), nprocs=world, join=True)
     for r in range(world):
         assert (tmp_path / f"rank{r}.txt").read_text() == "ok"
+
+
+def test_bin_ranges_cover_and_align():
+    """phase-2 bin ranges of the push exchange: consecutive, complete, multiples of the unit except the last"""
+    sys.path.insert(0, ROOT)
+    from spmv_openmp_cuda_amd.sharding import bin_ranges
+    for n, pieces, unit in [(610, 3, 256), (610, 8, 256), (1221, 4, 256), (19, 5, 1), (19, 3, 4), (5, 1, 256), (1, 8, 256),
+                            (4880, 2, 256), (256, 4, 256)]:
+        r = bin_ranges(n, pieces, unit)
+        assert r[0][0] == 0 and r[-1][1] == n and len(r) <= pieces
+        assert all(a[1] == b[0] for a, b in zip(r, r[1:]))
+        assert all((b - a) % unit == 0 for a, b in r[:-1]) and all(b > a for a, b in r)
+    assert bin_ranges(610, 3, 256) == [(0, 256), (256, 512), (512, 610)]
