@@ -629,7 +629,9 @@ int hipSpMVTilesCSR(spmat* dMat, double* dX, CONFIG cfg, double* dY) {
         return EXIT_SUCCESS;
     }
     if (!d->tiles && buildTiles(d)) return EXIT_FAILURE;
-    Launch L(dim3((unsigned)((d->M + 16383) / 16384)), dim3(1024));
+    uint32_t bins = 0, rowsPerBin = 0;
+    tilesShape(d, &bins, &rowsPerBin);
+    Launch L(dim3(bins), dim3(1024));                // phase 2's shape (phase 1: one workgroup per slice piece)
     if (enqueueTiles(d, dX, dY, S.stream)) { ERR("hipSpMVTilesCSR: launch failed"); return EXIT_FAILURE; }
     return L.finish("hipSpMVTilesCSR");
 }

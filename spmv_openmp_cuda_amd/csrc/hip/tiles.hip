@@ -47,12 +47,13 @@ namespace spmvhip {
 
 constexpr uint32_t PB_C_SHIFT = 14;                 // 16 Ki columns per slice = 128 KiB of x in LDS
 constexpr uint32_t PB_C       = 1u << PB_C_SHIFT;
-constexpr uint32_t PB_R_MAX_SHIFT = 14;             // <= 16 Ki rows per bin = 128 KiB of y in LDS
+constexpr uint32_t PB_R_MAX   = 20000;             // rows per bin: <= 156 KiB of y in LDS (160 KiB per CU on gfx950)
+constexpr uint32_t PB_CUS     = 256;               // compute units (phase 2 keeps one workgroup per CU)
 constexpr uint32_t PB_CHUNK   = 1u << 17;           // entries of one slice handled by one phase-1 workgroup
 constexpr int      PB_THREADS = 1024;
 
 struct TileFormat {
-    uint32_t S = 0, B = 0, rShift = 0;              // slices, bins, log2(rows per bin)
+    uint32_t S = 0, B = 0, R = 0;                   // slices, bins, rows per bin
     uint64_t nnz = 0;
     double*   val = nullptr;                        // slice-major values
     uint16_t* lcol = nullptr;                       // slice-major: column - slice*PB_C
@@ -95,13 +96,13 @@ __global__ __launch_bounds__(256) void pb_keys_kernel(uint64_t nnz, const uint32
 // along that order, so the first entry of a tile also fills the start of every empty tile before it.
 __global__ __launch_bounds__(256) void pb_bounds_kernel(
     uint64_t nnz, const uint32_t* __restrict__ perm, const uint16_t* __restrict__ skeys, const uint32_t* __restrict__ rowOf,
-    uint32_t B, uint32_t rShift, uint64_t nTiles, uint32_t* __restrict__ tileStart) {
+    uint32_t B, uint32_t R, uint64_t nTiles, uint32_t* __restrict__ tileStart) {
     const uint64_t p = lin_block() * 256 + threadIdx.x;
     if (p >= nnz) return;
-    const uint64_t t = (uint64_t)skeys[p] * B + (rowOf[perm[p]] >> rShift);
+    const uint64_t t = (uint64_t)skeys[p] * B + (rowOf[perm[p]] / R);
     uint64_t tPrev;                                  // tile of the previous entry, or "-1"
     if (p == 0) tPrev = ~0ull;
-    else tPrev = (uint64_t)skeys[p - 1] * B + (rowOf[perm[p - 1]] >> rShift);
+    else tPrev = (uint64_t)skeys[p - 1] * B + (rowOf[perm[p - 1]] / R);
     if (t != tPrev)
         for (uint64_t u = tPrev + 1; u <= t; ++u) tileStart[u] = (uint32_t)p;      // tPrev+1 wraps to 0 for p == 0
     if (p == nnz - 1)
@@ -141,16 +142,16 @@ __global__ __launch_bounds__(256) void pb_list_kernel(uint32_t S, uint32_t B, ui
 __global__ __launch_bounds__(256) void pb_gather_kernel(
     uint64_t nnz, const uint32_t* __restrict__ perm, const uint16_t* __restrict__ skeys,
     const uint32_t* __restrict__ rowOf, const uint32_t* __restrict__ JA, const double* __restrict__ AS,
-    uint32_t S, uint32_t B, uint32_t rShift, const uint32_t* __restrict__ tileStart, const uint32_t* __restrict__ bmStart,
+    uint32_t S, uint32_t B, uint32_t R, const uint32_t* __restrict__ tileStart, const uint32_t* __restrict__ bmStart,
     double* __restrict__ val, uint16_t* __restrict__ lcol, uint16_t* __restrict__ lrow) {
     const uint64_t p = lin_block() * 256 + threadIdx.x;
     if (p >= nnz) return;
     const uint32_t j = perm[p];
-    const uint32_t row = rowOf[j], bin = row >> rShift, slice = skeys[p];
+    const uint32_t row = rowOf[j], bin = row / R, slice = skeys[p];
     val[p] = AS[j];
     lcol[p] = (uint16_t)(JA[j] & (PB_C - 1));
     const uint32_t within = (uint32_t)p - tileStart[(uint64_t)slice * B + bin];
-    lrow[bmStart[(uint64_t)bin * S + slice] + within] = (uint16_t)(row & ((1u << rShift) - 1));
+    lrow[bmStart[(uint64_t)bin * S + slice] + within] = (uint16_t)(row - bin * R);
 }
 
 __global__ __launch_bounds__(256) void pb_fill_kernel(uint32_t* p, uint64_t n, uint32_t v) {
@@ -259,7 +260,7 @@ __global__ __launch_bounds__(PB_THREADS) void pb_expand_kernel(
 #endif
 constexpr int      P2_DEPTH = SPMV_P2_DEPTH;
 constexpr uint32_t P2_WAVES = PB_THREADS / 64;
-constexpr uint16_t P2_NONE  = 0xFFFF;               // "no entry" (local rows are < 2^14)
+constexpr uint16_t P2_NONE  = 0xFFFF;               // "no entry" (local rows are < PB_R_MAX)
 constexpr uint32_t TL_PAD   = 4;                    // sentinel records behind the list (the cursor reads 2 ahead)
 
 __host__ __device__ __forceinline__ uint32_t p2_sub(uint32_t len) { return ((len + P2_WAVES - 1) / P2_WAVES + 63u) & ~63u; }
@@ -297,11 +298,10 @@ __device__ __forceinline__ void p2_fetch(P2Regs& r, P2Cursor& c, uint32_t vbase,
 // is fused into the producing kernel as point-to-point stores, one 512-B run per wavefront instruction.
 template <bool MULTI>
 __global__ __launch_bounds__(PB_THREADS) void pb_reduce_kernel(
-    uint32_t rShift, uint32_t binBegin, uint32_t binEnd, uint64_t M, const uint32_t* __restrict__ binPos, const uint32_t* __restrict__ waveTile,
+    uint32_t R, uint32_t binBegin, uint32_t binEnd, uint64_t M, const uint32_t* __restrict__ binPos, const uint32_t* __restrict__ waveTile,
     const uint2* __restrict__ tl, const double* __restrict__ prod, const uint16_t* __restrict__ lrow,
     double* __restrict__ y, TileDst extra) {
     extern __shared__ double yb[];                  // R doubles
-    const uint32_t R = 1u << rShift;
 #ifdef SPMV_P2_XCD      // tuning: give every XCD a contiguous range of bins (workgroups are dealt round-robin to the 8 XCDs)
     const uint32_t nBins = binEnd - binBegin;
     const uint64_t i_ = lin_block();
@@ -343,7 +343,7 @@ __global__ __launch_bounds__(PB_THREADS) void pb_reduce_kernel(
         }
     }
     __syncthreads();
-    const uint64_t r0 = bin << rShift;
+    const uint64_t r0 = bin * R;
     for (uint32_t k = threadIdx.x; k < R; k += PB_THREADS)
         if (r0 + k < M) y[r0 + k] = yb[k];
     if (MULTI) {
@@ -403,16 +403,24 @@ int buildTiles(DevMat* d) {
     if (S64 > 65535) { fprintf(stderr, "libspmvhip: tiles: %lu columns exceed 65535 slices\n", (unsigned long)N); return EXIT_FAILURE; }
     TileFormat* t = new TileFormat;
     t->S = (uint32_t)S64;
-    // rows per bin: as large as LDS allows (longer tiles = longer contiguous runs in phase 2); halve it while
-    // there are fewer than ~1024 bins (phase 2 should fill the chip several times over) AND the tiles would
-    // still average >= 64 entries.  Measured: c3 (10 M x 10 M) 8 Ki rows 1.27 ms vs 16 Ki 1.35 ms; a
-    // 10 M x 80 M shard of c5 16 Ki 1.44 ms, 8 Ki 1.50 ms, 4 Ki 1.95 ms.
-    uint32_t rShift = PB_R_MAX_SHIFT;
-    auto binsAt = [&](uint32_t sh) { return (M + (1ull << sh) - 1) >> sh; };
-    while (rShift > 10 && binsAt(rShift) < 1024 && nnz / ((uint64_t)t->S * binsAt(rShift - 1)) >= 64) --rShift;
-    if (const char* e = getenv("SPMV_PB_RSHIFT")) { const int v = atoi(e); if (v >= 10 && v <= (int)PB_R_MAX_SHIFT) rShift = (uint32_t)v; }   // tuning only
-    t->rShift = rShift;
-    t->B = (uint32_t)((M + (1ull << rShift) - 1) >> rShift);
+    // Rows per bin R (any value up to PB_R_MAX, not a power of two): phase 2 runs ONE workgroup per CU at a time (its
+    // bin of y fills the LDS), so the bins are processed in rounds of PB_CUS and a partly filled last round leaves
+    // most of the chip idle -- 610 bins of 16 Ki rows on 256 CUs are 2.4 rounds of work in the time of ~2.7.  For
+    // matrices of up to a few thousand bins R is therefore chosen so that the bin count is a multiple of PB_CUS
+    // (10 M rows: 512 bins of 19 532 rows = exactly two rounds, and 20 % longer tiles); beyond that the tail is
+    // negligible and R is simply the largest that fits.  Measured (this box, ms): see DESIGN.md section 7.
+    uint32_t R = PB_R_MAX;
+    {
+        const uint64_t bMin = (M + PB_R_MAX - 1) / PB_R_MAX;
+        if (bMin <= 8 * PB_CUS) {
+            const uint64_t b = (bMin + PB_CUS - 1) / PB_CUS * PB_CUS;
+            R = (uint32_t)std::max<uint64_t>(64, ((M + b - 1) / b + 63) / 64 * 64);
+            R = std::min(R, PB_R_MAX);
+        }
+    }
+    if (const char* e = getenv("SPMV_PB_ROWS")) { const int v = atoi(e); if (v >= 64 && v <= (int)PB_R_MAX) R = (uint32_t)v; }   // tuning only
+    t->R = R;
+    t->B = (uint32_t)((M + R - 1) / R);
     t->nnz = nnz;
     const uint64_t nTiles = (uint64_t)t->S * t->B;
     if (nTiles >= (1ull << 32) - 2) { fprintf(stderr, "libspmvhip: tiles: too many tiles\n"); delete t; return EXIT_FAILURE; }
@@ -444,7 +452,7 @@ int buildTiles(DevMat* d) {
                                      perm.as<uint32_t>(), (size_t)nnz, 0, bits, (hipStream_t) nullptr));
 
     hipLaunchKernelGGL(pb_bounds_kernel, grid2d((nnz + 255) / 256, 256), dim3(256), 0, nullptr, nnz, perm.as<uint32_t>(),
-                       keysOut.as<uint16_t>(), rowOf.as<uint32_t>(), t->B, rShift, nTiles, tileStart.as<uint32_t>());
+                       keysOut.as<uint16_t>(), rowOf.as<uint32_t>(), t->B, t->R, nTiles, tileStart.as<uint32_t>());
     PB_TRY(hipGetLastError());
     // bin-major view: tile lengths (bin-major) -> exclusive scans give every tile's bin-major start and its index
     // in the list of non-empty tiles
@@ -473,7 +481,7 @@ int buildTiles(DevMat* d) {
                            tileStart.as<uint32_t>(), lens.as<uint32_t>(), bmStart.as<uint32_t>(), listIdx.as<uint32_t>(), t->nList,
                            t->tl, t->binPos, binTile.as<uint32_t>());
         hipLaunchKernelGGL(pb_gather_kernel, grid2d((nnz + 255) / 256, 256), dim3(256), 0, nullptr, nnz, perm.as<uint32_t>(),
-                           keysOut.as<uint16_t>(), rowOf.as<uint32_t>(), d->JA, d->AS, t->S, t->B, rShift, tileStart.as<uint32_t>(),
+                           keysOut.as<uint16_t>(), rowOf.as<uint32_t>(), d->JA, d->AS, t->S, t->B, t->R, tileStart.as<uint32_t>(),
                            bmStart.as<uint32_t>(), t->val, t->lcol, t->lrow);
         hipLaunchKernelGGL(pb_wavetile_kernel, grid2d(((uint64_t)t->B * P2_WAVES + 255) / 256, 256), dim3(256), 0, nullptr, t->B,
                            t->binPos, binTile.as<uint32_t>(), t->tl, t->waveTile);
@@ -509,8 +517,8 @@ int buildTiles(DevMat* d) {
     static bool attrSet = false;
     if (!attrSet) {
         PB_TRY(hipFuncSetAttribute((const void*)pb_expand_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, PB_C * 8));
-        PB_TRY(hipFuncSetAttribute((const void*)pb_reduce_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (1 << PB_R_MAX_SHIFT) * 8));
-        PB_TRY(hipFuncSetAttribute((const void*)pb_reduce_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (1 << PB_R_MAX_SHIFT) * 8));
+        PB_TRY(hipFuncSetAttribute((const void*)pb_reduce_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, PB_R_MAX * 8));
+        PB_TRY(hipFuncSetAttribute((const void*)pb_reduce_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, PB_R_MAX * 8));
         attrSet = true;
     }
     d->tiles = t;
@@ -521,7 +529,7 @@ size_t tilesBytes(const DevMat* d) { return d->tiles ? d->tiles->bytes : 0; }
 
 void tilesShape(const DevMat* d, uint32_t* bins, uint32_t* rowsPerBin) {
     *bins = d->tiles ? d->tiles->B : 0;
-    *rowsPerBin = d->tiles ? 1u << d->tiles->rShift : 0;
+    *rowsPerBin = d->tiles ? d->tiles->R : 0;
 }
 
 // phase 1 on `stream`: products of the whole matrix into the format's workspace
@@ -545,11 +553,11 @@ int enqueueTilesReduce(DevMat* d, uint32_t binBegin, uint32_t binEnd, double* y,
     dst.n = (uint32_t)nExtra;
     for (int i = 0; i < nExtra; ++i) dst.p[i] = extra[i];
     if (nExtra)
-        hipLaunchKernelGGL(pb_reduce_kernel<true>, grid, dim3(PB_THREADS), (size_t)8 << t->rShift, stream,
-                           t->rShift, binBegin, binEnd, d->M, t->binPos, t->waveTile, t->tl, t->prod, t->lrow, y, dst);
+        hipLaunchKernelGGL(pb_reduce_kernel<true>, grid, dim3(PB_THREADS), (size_t)8 * t->R, stream,
+                           t->R, binBegin, binEnd, d->M, t->binPos, t->waveTile, t->tl, t->prod, t->lrow, y, dst);
     else
-        hipLaunchKernelGGL(pb_reduce_kernel<false>, grid, dim3(PB_THREADS), (size_t)8 << t->rShift, stream,
-                           t->rShift, binBegin, binEnd, d->M, t->binPos, t->waveTile, t->tl, t->prod, t->lrow, y, dst);
+        hipLaunchKernelGGL(pb_reduce_kernel<false>, grid, dim3(PB_THREADS), (size_t)8 * t->R, stream,
+                           t->R, binBegin, binEnd, d->M, t->binPos, t->waveTile, t->tl, t->prod, t->lrow, y, dst);
     return hipGetLastError() == hipSuccess ? EXIT_SUCCESS : EXIT_FAILURE;
 }
 
