@@ -35,6 +35,7 @@
 // keeps the (row, column) order of the CSR inside every slice.
 #include <hip/hip_runtime.h>
 #include <cstring>
+#include <cmath>
 #include <rocprim/device/device_radix_sort.hpp>
 #include <rocprim/device/device_scan.hpp>
 #include <algorithm>
@@ -494,13 +495,35 @@ int buildTiles(DevMat* d) {
     std::vector<uint32_t> sliceStart(t->S + 1);
     PB_TRY(hipMemcpy2D(sliceStart.data(), 4, tileStart.as<uint32_t>(), (size_t)t->B * 4, 4, t->S + 1, hipMemcpyDeviceToHost));
     std::vector<uint3> work;
+    // Work item size.  One workgroup per CU at a time (the x slice fills the LDS), so the items are processed in rounds
+    // of PB_CUS and what counts is (a) items of 50-100 k entries (c5: 524 k 8.88 ms, 262 k 8.82, 131 k 8.76, 65-98 k
+    // 8.74) and (b) how full the LAST round is: on c3 (610 slices of 328 k entries) 3 pieces per slice = 7.15 rounds ran
+    // at 1.081 ms, 2 / 4 / 6 pieces (4.77 / 9.53 / 14.3 rounds) at 1.041-1.046 ms.  The extra x-slice fills of more pieces
+    // are nearly free (issued under the running stream, served by L2 / Infinity Cache).  Pieces per slice: within the
+    // 50-100 k window, minimise  0.35 * idle share of the last round + a tenth of the relative fill traffic.
+    uint32_t chunk = PB_CHUNK;
+    {
+        uint64_t nonEmpty = 0;
+        for (uint32_t s = 0; s < t->S; ++s) nonEmpty += sliceStart[s + 1] > sliceStart[s];
+        const double avgLen = nonEmpty ? (double)nnz / (double)nonEmpty : 1.0;
+        double bestCost = 1e300;
+        const uint32_t pLo = (uint32_t)std::max(1.0, std::ceil(avgLen / 100000.0));
+        const uint32_t pHi = (uint32_t)std::max((double)pLo, std::ceil(avgLen / 50000.0));
+        for (uint32_t p = pLo; p <= std::min<uint32_t>(pHi, 1024); ++p) {
+            const double rounds = (double)nonEmpty * p / PB_CUS;
+            const double waste = (std::ceil(rounds) - rounds) / rounds;
+            const double cost = 0.35 * waste + 0.1 * p * (PB_C * 8.0) / (avgLen * 18.0);
+            if (cost < bestCost) { bestCost = cost; chunk = (uint32_t)std::min(16777216.0, std::ceil(avgLen / p * 1.02) + 64); }
+        }
+    }
+    if (const char* e = getenv("SPMV_PB_CHUNK")) { const long v = atol(e); if (v >= 4096 && v <= (1l << 24)) chunk = (uint32_t)v; }   // tuning only
     for (uint32_t s = 0; s < t->S; ++s) {
         // a slice is cut into equal pieces of at most PB_CHUNK entries (a fixed chunk size + remainder left one
         // short, fill-dominated work item per slice); inner boundaries fall on multiples of 64 entries so that
         // only a slice's first work item has a scalar head
         const uint32_t b0 = sliceStart[s], e0 = sliceStart[s + 1], len = e0 - b0;
         if (!len) continue;
-        const uint32_t pieces = (len + PB_CHUNK - 1) / PB_CHUNK;
+        const uint32_t pieces = (len + chunk - 1) / chunk;
         const uint32_t piece = (len + pieces - 1) / pieces;
         uint32_t b = b0;
         for (uint32_t k = 1; k <= pieces && b < e0; ++k) {
