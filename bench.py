@@ -96,14 +96,15 @@ AUTO_CANDIDATES = ("hipSpMVWarpPerRowCSR", "hipSpMVTilesCSR", "hipSpMVRowsSELL")
 THREAD_PER_ROW = ("hipSpMVRowsCSR", "hipSpMVRowsSELL")      # both add a row's products in ascending j with one lane
 
 
-def pick_launcher(api, torch, dm, x_ptr, y_ptr, requested, candidates=None):
+def pick_launcher(api, torch, dm, x_ptr, y_ptr, requested, eligible=None):
     """'auto' -> run each candidate 3x (first call of the tiles launcher also builds its
-    slice-major format) and keep the faster; returns (name, {name: ms})."""
+    slice-major format) and keep the fastest of the `eligible` ones (default: all); the others
+    are timed for information.  Returns (name, {name: ms})."""
     if requested != "auto":
         return requested, {}
     cfg = api.CONFIG()
     times = {}
-    for name in (candidates or AUTO_CANDIDATES):
+    for name in dict.fromkeys(tuple(eligible or ()) + AUTO_CANDIDATES):
         fn = api.SPMV_LAUNCHERS[name]
         if fn(C.byref(dm.handle), x_ptr, cfg, y_ptr):
             continue                                  # e.g. tiles unsupported for this shape: skip
@@ -113,7 +114,7 @@ def pick_launcher(api, torch, dm, x_ptr, y_ptr, requested, candidates=None):
             fn(C.byref(dm.handle), x_ptr, cfg, y_ptr)
         torch.cuda.synchronize()
         times[name] = (time.perf_counter() - t0) / 3 * 1e3
-    best = min(times, key=times.get)
+    best = min((n for n in times if not eligible or n in eligible), key=times.get)
     return best, times
 
 
@@ -165,6 +166,7 @@ def measure_single(api, synth, torch, w, launcher, steps, warmup, candidates=Non
     k_avg = sum(kms) / len(kms) * 1e-3
     res = {
         "workload": info, "launcher": launcher, "auto_candidates_ms": tried,
+        "eligible_launchers": list(candidates) if candidates else "all",
         "extra_device_bytes": int(api.lib.spmvHipTilesBytes(C.byref(dm.handle))) if launcher == "hipSpMVTilesCSR" else
                               int(api.lib.spmvHipSellBytes(C.byref(dm.handle))) if launcher == "hipSpMVRowsSELL" else 0,
         "ms_per_step": wall / steps * 1e3, "kernel_ms_avg": k_avg * 1e3, "kernel_ms_min": min(kms),

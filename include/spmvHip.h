@@ -108,8 +108,10 @@ SPMV_HIP hipSpMVWarpsPerRowELLNTrasposed; /* <- cudaSpMVWarpsPerRowELLNTrasposed
  * (DESIGN.md section 7): the GPU counterpart of the reference's 2-D decomposed
  * CPU variants spmvTilesCSR / spmvTilesAllocdCSR (src/SpMV_CSR_OMP.c:101-226:
  * column partitions, partial results, final reduction).  The slice-major copy
- * of the matrix (+20 B/nnz of device memory) is built on the device at the
- * first call, or explicitly with spmvHipBuildTiles.  Row sums are added in
+ * of the matrix (+12 B/nnz of device memory per matrix, plus ONE product
+ * workspace of 8 B/nnz of the largest matrix, shared by all matrices of the
+ * device and used in stream order) is built on the device at the first call, or
+ * explicitly with spmvHipBuildTiles.  Row sums are added in
  * arrival order (LDS atomics): equal to the oracle to rounding, not bitwise. */
 SPMV_HIP hipSpMVTilesCSR;
 int    spmvHipBuildTiles(spmat* dMat);

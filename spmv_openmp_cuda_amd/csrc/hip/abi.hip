@@ -358,6 +358,7 @@ int spmvHipInit(int dev, size_t sizeofSpmat, size_t sizeofConfig) {
 int spmvHipFinalize(void) {
     if (!S.inited) return EXIT_SUCCESS;
     spmvHipDropCache();
+    freeTilesWorkspace();
     if (S.ev0) (void)hipEventDestroy(S.ev0);
     if (S.ev1) (void)hipEventDestroy(S.ev1);
     S.ev0 = S.ev1 = nullptr;

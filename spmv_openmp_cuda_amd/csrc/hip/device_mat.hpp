@@ -66,6 +66,7 @@ size_t sellBytes(const DevMat* d);
 
 int  buildTiles(DevMat* d);                                     // tiles.hip
 void freeTiles(TileFormat* t);
+void freeTilesWorkspace();                                      // the per-device product workspace (8 B/nnz of the largest matrix)
 int  enqueueTiles(DevMat* d, const double* x, double* y, hipStream_t stream);
 int  enqueueTilesExpand(DevMat* d, const double* x, hipStream_t stream);
 int  enqueueTilesReduce(DevMat* d, uint32_t binBegin, uint32_t binEnd, double* y, int nExtra, double* const* extra, hipStream_t stream);

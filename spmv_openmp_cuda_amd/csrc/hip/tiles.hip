@@ -52,6 +52,7 @@ constexpr uint32_t PB_R_MAX   = 20000;             // rows per bin: <= 156 KiB o
 constexpr uint32_t PB_CUS     = 256;               // compute units (phase 2 keeps one workgroup per CU)
 constexpr uint32_t PB_CHUNK   = 1u << 17;           // entries of one slice handled by one phase-1 workgroup
 constexpr int      PB_THREADS = 1024;
+constexpr size_t   PB_RESIDENT_BYTES = 288ull << 20; // products up to this size stay in the 256 MiB Infinity Cache between the phases (c2, 244 MiB: 0.156 ms plain vs 0.176 ms nt stores)
 
 struct TileFormat {
     uint32_t S = 0, B = 0, R = 0;                   // slices, bins, rows per bin
@@ -66,7 +67,7 @@ struct TileFormat {
     uint32_t* waveTile = nullptr;                   // [B * waves] tile-list index where each wavefront of phase 2 starts
     uint3*    work = nullptr;                       // phase-1 work items {slice, begin, end}
     uint32_t  nWork = 0;
-    double*   prod = nullptr;                       // products, slice-major (workspace)
+    bool      ntStore = true;                       // phase 1 stores the products non-temporally (streams larger than the Infinity Cache)
     size_t    bytes = 0;
 };
 
@@ -191,6 +192,7 @@ __device__ __forceinline__ void p1_load(P1Regs& r, uint32_t p, uint32_t ve, cons
     }
 }
 
+template <bool NT>
 __device__ __forceinline__ void p1_store(const P1Regs& r, uint32_t p, uint32_t ve, const double* xs, double* __restrict__ prod) {
 #pragma unroll
     for (int u = 0; u < P1_DEPTH; ++u) {
@@ -198,11 +200,12 @@ __device__ __forceinline__ void p1_store(const P1Regs& r, uint32_t p, uint32_t v
         if (q < ve) {
             dbl2 o;
             o.x = r.a[u].x * xs[r.c[u].x]; o.y = r.a[u].y * xs[r.c[u].y];
-            __builtin_nontemporal_store(o, (dbl2*)(prod + q));
+            if (NT) __builtin_nontemporal_store(o, (dbl2*)(prod + q)); else *(dbl2*)(prod + q) = o;
         }
     }
 }
 
+template <bool NT>
 __global__ __launch_bounds__(PB_THREADS) void pb_expand_kernel(
     const uint3* __restrict__ work, const double* __restrict__ val, const uint16_t* __restrict__ lcol,
     const double* __restrict__ x, uint64_t N, double* __restrict__ prod) {
@@ -238,9 +241,9 @@ __global__ __launch_bounds__(PB_THREADS) void pb_expand_kernel(
         constexpr uint32_t BATCH = P1_DEPTH * P1_STEP;
         for (; p < ve; p += 2 * BATCH) {
             p1_load(nxt, p + BATCH, ve, val, lcol);
-            p1_store(cur, p, ve, xs, prod);
+            p1_store<NT>(cur, p, ve, xs, prod);
             p1_load(cur, p + 2 * BATCH, ve, val, lcol);
-            p1_store(nxt, p + BATCH, ve, xs, prod);
+            p1_store<NT>(nxt, p + BATCH, ve, xs, prod);
         }
     }
 }
@@ -388,10 +391,39 @@ struct TempBuf {
 
 }  // namespace
 
+// The products live in ONE workspace per device, shared by every matrix of the process: phase 1 of a matrix fills
+// it, phase 2 of the same matrix empties it, and launches are ordered on the library stream.  Re-using the same
+// addresses matters when a matrix is processed as several row groups whose products fit the 256 MiB Infinity
+// Cache: the lines are overwritten while still cached instead of being written back to HBM and re-allocated
+// (scripts/microbench_mall.hip: write-then-read of a 128 MiB buffer 6.6 TB/s, of a 2 GiB one 4.9-5.1 TB/s).
+struct ProdWorkspace { double* p = nullptr; size_t cap = 0; };
+static ProdWorkspace g_prod[16];
+
+static double* prodWorkspace(size_t n, bool grow) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
+    ProdWorkspace& w = g_prod[dev];
+    if (n <= w.cap || !grow) return n <= w.cap ? w.p : nullptr;
+    (void)hipDeviceSynchronize();                   // nothing may still read the old buffer
+    if (w.p) (void)hipFree(w.p);
+    w.p = nullptr; w.cap = 0;
+    if (hipMalloc(&w.p, n * sizeof(double)) != hipSuccess) { w.p = nullptr; return nullptr; }
+    w.cap = n;
+    return w.p;
+}
+
+void freeTilesWorkspace() {
+    int keep = 0;
+    (void)hipGetDevice(&keep);
+    for (int d = 0; d < 16; ++d)
+        if (g_prod[d].p) { (void)hipSetDevice(d); (void)hipFree(g_prod[d].p); g_prod[d] = ProdWorkspace{}; }
+    (void)hipSetDevice(keep);
+}
+
 void freeTiles(TileFormat* t) {
     if (!t) return;
     (void)hipFree(t->val); (void)hipFree(t->lcol); (void)hipFree(t->lrow); (void)hipFree(t->tl);
-    (void)hipFree(t->binPos); (void)hipFree(t->waveTile); (void)hipFree(t->work); (void)hipFree(t->prod);
+    (void)hipFree(t->binPos); (void)hipFree(t->waveTile); (void)hipFree(t->work);
     delete t;
 }
 
@@ -432,7 +464,7 @@ int buildTiles(DevMat* d) {
         tileStart.alloc((nTiles + 2) * 4))
         return fail("temporary allocation");
     if (hipMalloc(&t->val, nnz * 8) || hipMalloc(&t->lcol, nnz * 2) || hipMalloc(&t->lrow, nnz * 2) ||
-        hipMalloc(&t->prod, nnz * 8) || hipMalloc(&t->binPos, ((size_t)t->B + 1) * 4) ||
+        !prodWorkspace(nnz, true) || hipMalloc(&t->binPos, ((size_t)t->B + 1) * 4) ||
         hipMalloc(&t->waveTile, (size_t)t->B * P2_WAVES * 4))
         return fail("format allocation");
 
@@ -489,7 +521,7 @@ int buildTiles(DevMat* d) {
         PB_TRY(hipGetLastError());
         PB_TRY(hipDeviceSynchronize());
     }
-    t->bytes = nnz * 20 + ((size_t)t->nList + TL_PAD) * 8 + ((size_t)t->B + 1) * 4 + (size_t)t->B * P2_WAVES * 4;
+    t->bytes = nnz * 12 + ((size_t)t->nList + TL_PAD) * 8 + ((size_t)t->B + 1) * 4 + (size_t)t->B * P2_WAVES * 4;
 
     // phase-1 work list from the slice boundaries (tileStart[s*B])
     std::vector<uint32_t> sliceStart(t->S + 1);
@@ -539,11 +571,17 @@ int buildTiles(DevMat* d) {
 
     static bool attrSet = false;
     if (!attrSet) {
-        PB_TRY(hipFuncSetAttribute((const void*)pb_expand_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, PB_C * 8));
+        PB_TRY(hipFuncSetAttribute((const void*)pb_expand_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, PB_C * 8));
+        PB_TRY(hipFuncSetAttribute((const void*)pb_expand_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, PB_C * 8));
         PB_TRY(hipFuncSetAttribute((const void*)pb_reduce_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, PB_R_MAX * 8));
         PB_TRY(hipFuncSetAttribute((const void*)pb_reduce_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, PB_R_MAX * 8));
         attrSet = true;
     }
+    // products that fit the Infinity Cache (with room for x and the streams) are stored with the default policy so
+    // that phase 2 finds them there; larger streams bypass it (microbench_mall.hip: resident 7.0 vs 5.8 TB/s with
+    // non-temporal stores; non-resident 4.9 vs 5.1-5.4)
+    t->ntStore = nnz * 8 > PB_RESIDENT_BYTES;
+    if (const char* e = getenv("SPMV_PB_NTSTORE")) t->ntStore = atoi(e) != 0;                         // tuning only
     d->tiles = t;
     return EXIT_SUCCESS;
 }
@@ -559,9 +597,16 @@ void tilesShape(const DevMat* d, uint32_t* bins, uint32_t* rowsPerBin) {
 int enqueueTilesExpand(DevMat* d, const double* x, hipStream_t stream) {
     TileFormat* t = d->tiles;
     if (!t) return EXIT_FAILURE;
-    if (t->nWork)
-        hipLaunchKernelGGL(pb_expand_kernel, grid2d(t->nWork, PB_THREADS), dim3(PB_THREADS), PB_C * 8, stream, t->work, t->val,
-                           t->lcol, x, d->N, t->prod);
+    double* prod = prodWorkspace(t->nnz, true);      // grows (after a device synchronise) only if it was released meanwhile
+    if (!prod) return EXIT_FAILURE;
+    if (t->nWork) {
+        if (t->ntStore)
+            hipLaunchKernelGGL(pb_expand_kernel<true>, grid2d(t->nWork, PB_THREADS), dim3(PB_THREADS), PB_C * 8, stream, t->work, t->val,
+                               t->lcol, x, d->N, prod);
+        else
+            hipLaunchKernelGGL(pb_expand_kernel<false>, grid2d(t->nWork, PB_THREADS), dim3(PB_THREADS), PB_C * 8, stream, t->work, t->val,
+                               t->lcol, x, d->N, prod);
+    }
     return hipGetLastError() == hipSuccess ? EXIT_SUCCESS : EXIT_FAILURE;
 }
 
@@ -572,15 +617,17 @@ int enqueueTilesReduce(DevMat* d, uint32_t binBegin, uint32_t binEnd, double* y,
     if (!t || binBegin > binEnd || binEnd > t->B || nExtra < 0 || nExtra > SPMV_MAX_PEERS) return EXIT_FAILURE;
     if (binBegin == binEnd) return EXIT_SUCCESS;
     const dim3 grid = grid2d((uint64_t)((binEnd - binBegin + 7) / 8) * 8, PB_THREADS);
+    const double* prod = prodWorkspace(t->nnz, false);
+    if (!prod) return EXIT_FAILURE;
     TileDst dst{};
     dst.n = (uint32_t)nExtra;
     for (int i = 0; i < nExtra; ++i) dst.p[i] = extra[i];
     if (nExtra)
         hipLaunchKernelGGL(pb_reduce_kernel<true>, grid, dim3(PB_THREADS), (size_t)8 * t->R, stream,
-                           t->R, binBegin, binEnd, d->M, t->binPos, t->waveTile, t->tl, t->prod, t->lrow, y, dst);
+                           t->R, binBegin, binEnd, d->M, t->binPos, t->waveTile, t->tl, prod, t->lrow, y, dst);
     else
         hipLaunchKernelGGL(pb_reduce_kernel<false>, grid, dim3(PB_THREADS), (size_t)8 * t->R, stream,
-                           t->R, binBegin, binEnd, d->M, t->binPos, t->waveTile, t->tl, t->prod, t->lrow, y, dst);
+                           t->R, binBegin, binEnd, d->M, t->binPos, t->waveTile, t->tl, prod, t->lrow, y, dst);
     return hipGetLastError() == hipSuccess ? EXIT_SUCCESS : EXIT_FAILURE;
 }
 
