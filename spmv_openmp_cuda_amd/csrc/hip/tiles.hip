@@ -265,6 +265,7 @@ __global__ __launch_bounds__(PB_THREADS) void pb_expand_kernel(
 constexpr int      P2_DEPTH = SPMV_P2_DEPTH;
 constexpr uint32_t P2_WAVES = PB_THREADS / 64;
 constexpr uint16_t P2_NONE  = 0xFFFF;               // "no entry" (local rows are < PB_R_MAX)
+constexpr uint32_t P2_RUNS_FLAG = 0x80000000u;      // in waveTile[]: this wavefront's range holds runs of equal rows
 constexpr uint32_t TL_PAD   = 4;                    // sentinel records behind the list (the cursor reads 2 ahead)
 
 __host__ __device__ __forceinline__ uint32_t p2_sub(uint32_t len) { return ((len + P2_WAVES - 1) / P2_WAVES + 63u) & ~63u; }
@@ -297,6 +298,41 @@ __device__ __forceinline__ void p2_fetch(P2Regs& r, P2Cursor& c, uint32_t vbase,
     }
 }
 
+// One step of 64 entries into the bin.  Entries of one row are neighbours in the bin-major order (a tile is sorted by
+// row), so on matrices with clustered columns -- and in the heavy rows of the power-law ones -- many lanes of a
+// wavefront carry the SAME row and their ds_add_f64 serialise on one LDS address (band +-16 Ki: phase 2 660 us
+// against 376 us for the same matrix with uniform columns).  Runs of equal rows are therefore summed in registers
+// first -- a segmented suffix sum inside each 16-lane DPP row, 4 shift-and-add steps -- and only the first lane of a
+// run adds to LDS.  Whether a wavefront's range is worth it is decided when the format is built (at least one
+// entry in eight repeats its predecessor's row) and kept as a flag in waveTile[]: ranges without runs -- all of them
+// on uniform columns -- run the plain loop at no cost (testing every step in the kernel cost 2-7 % there).
+template <int D>
+__device__ __forceinline__ double p2_shl(double v) {            // value of lane + D inside the 16-lane row, else 0
+    const uint64_t b = __double_as_longlong(v);
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)b, 0x100 + D, 0xF, 0xF, false);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(b >> 32), 0x100 + D, 0xF, 0xF, false);
+    return __longlong_as_double(((uint64_t)hi << 32) | lo);
+}
+
+__device__ __forceinline__ uint32_t p2_prev_row(uint32_t row) {  // row of lane - 1 inside the 16-lane row; lane % 16 == 0 gets ~0
+    return (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)row, 0x111, 0xF, 0xF, false);
+}
+
+__device__ __forceinline__ void p2_add_runs(double* yb, uint16_t rv, double pv, uint32_t lane) {
+    const uint32_t row = rv;
+    const bool follows = row == p2_prev_row(row) && row != P2_NONE;
+    const uint64_t dup = __builtin_amdgcn_ballot_w64(follows);
+    const uint64_t m = (~dup >> 1) >> lane;                      // run starts behind this lane
+    const uint32_t e = m ? lane + 1u + (uint32_t)__builtin_ctzll(m) : 64u;     // where this lane's run ends
+    double v = rv != P2_NONE ? pv : 0.0;
+    double t;
+    t = p2_shl<1>(v); v += lane + 1 < e ? t : 0.0;
+    t = p2_shl<2>(v); v += lane + 2 < e ? t : 0.0;
+    t = p2_shl<4>(v); v += lane + 4 < e ? t : 0.0;
+    t = p2_shl<8>(v); v += lane + 8 < e ? t : 0.0;
+    if (!follows && rv != P2_NONE) atomicAdd(&yb[rv], v);
+}
+
 // MULTI: the finished bin of y is also stored to `extra.n` further destinations -- the copies of y that the other
 // ranks of a multi-GPU run hold, mapped into this process (peer windows over xGMI, peer.hip): the all-gather of y
 // is fused into the producing kernel as point-to-point stores, one 512-B run per wavefront instruction.
@@ -322,9 +358,12 @@ __global__ __launch_bounds__(PB_THREADS) void pb_reduce_kernel(
     const uint32_t wb = v0 + wave * sub, we = min(v1, wb + sub);
     P2Cursor c;
     P2Regs a, b;
+    bool runs = false;                               // uniform per wavefront
     const bool busy = wave * sub < v1 - v0;          // uniform per wavefront
     if (busy) {
-        c.k = waveTile[bin * P2_WAVES + wave];
+        const uint32_t wt = waveTile[bin * P2_WAVES + wave];
+        runs = (wt & P2_RUNS_FLAG) != 0;
+        c.k = wt & ~P2_RUNS_FLAG;
         c.delta = tl[c.k].y;
         c.n1 = tl[c.k + 1];
         c.n2 = tl[c.k + 2];
@@ -335,15 +374,26 @@ __global__ __launch_bounds__(PB_THREADS) void pb_reduce_kernel(
     if (busy) {
         // ping-pong between the two register batches (an `a = b` copy would need b's loads to have landed, i.e.
         // a full wait at the end of every iteration); batches past the end hold nothing but P2_NONE
-        for (uint32_t v = wb; v < we; v += 2 * P2_DEPTH * 64) {
-            p2_fetch(b, c, v + P2_DEPTH * 64, we, lane, tl, prod, lrow);
+        if (!runs) {
+            for (uint32_t v = wb; v < we; v += 2 * P2_DEPTH * 64) {
+                p2_fetch(b, c, v + P2_DEPTH * 64, we, lane, tl, prod, lrow);
 #pragma unroll
-            for (int u = 0; u < P2_DEPTH; ++u)
-                if (a.rv[u] != P2_NONE) atomicAdd(&yb[a.rv[u]], a.pv[u]);
-            p2_fetch(a, c, v + 2 * P2_DEPTH * 64, we, lane, tl, prod, lrow);
+                for (int u = 0; u < P2_DEPTH; ++u)
+                    if (a.rv[u] != P2_NONE) atomicAdd(&yb[a.rv[u]], a.pv[u]);
+                p2_fetch(a, c, v + 2 * P2_DEPTH * 64, we, lane, tl, prod, lrow);
 #pragma unroll
-            for (int u = 0; u < P2_DEPTH; ++u)
-                if (b.rv[u] != P2_NONE) atomicAdd(&yb[b.rv[u]], b.pv[u]);
+                for (int u = 0; u < P2_DEPTH; ++u)
+                    if (b.rv[u] != P2_NONE) atomicAdd(&yb[b.rv[u]], b.pv[u]);
+            }
+        } else {                                     // this wavefront's entries come in runs of equal rows
+            for (uint32_t v = wb; v < we; v += 2 * P2_DEPTH * 64) {
+                p2_fetch(b, c, v + P2_DEPTH * 64, we, lane, tl, prod, lrow);
+#pragma unroll
+                for (int u = 0; u < P2_DEPTH; ++u) p2_add_runs(yb, a.rv[u], a.pv[u], lane);
+                p2_fetch(a, c, v + 2 * P2_DEPTH * 64, we, lane, tl, prod, lrow);
+#pragma unroll
+                for (int u = 0; u < P2_DEPTH; ++u) p2_add_runs(yb, b.rv[u], b.pv[u], lane);
+            }
         }
     }
     __syncthreads();
@@ -365,19 +415,36 @@ __global__ __launch_bounds__(PB_THREADS) void pb_reduce_kernel(
 // the wavefront's first position
 __global__ __launch_bounds__(256) void pb_wavetile_kernel(uint32_t B, const uint32_t* __restrict__ binPos,
                                                           const uint32_t* __restrict__ binTile, const uint2* __restrict__ tl,
-                                                          uint32_t* __restrict__ waveTile) {
+                                                          const uint32_t* __restrict__ dupCount, uint32_t* __restrict__ waveTile) {
     const uint64_t i = lin_block() * 256 + threadIdx.x;
     if (i >= (uint64_t)B * P2_WAVES) return;
     const uint32_t b = (uint32_t)(i / P2_WAVES), wv = (uint32_t)(i % P2_WAVES);
     const uint32_t v0 = binPos[b], v1 = binPos[b + 1];
-    const uint32_t wb = v0 + wv * p2_sub(v1 - v0);
+    const uint32_t sub = p2_sub(v1 - v0);
+    const uint32_t wb = v0 + wv * sub;
     uint32_t lo = binTile[b], hi = binTile[b + 1];  // answer in [lo, hi)
     if (wb >= v1 || lo >= hi) { waveTile[i] = lo; return; }
     while (hi - lo > 1) {
         const uint32_t mid = lo + (hi - lo) / 2;
         if (tl[mid].x <= wb) lo = mid; else hi = mid;
     }
-    waveTile[i] = lo;
+    const uint32_t len = min(v1, wb + sub) - wb;
+    waveTile[i] = lo | (dupCount[i] * 8 >= len ? P2_RUNS_FLAG : 0u);
+}
+
+// entries that repeat the row of their predecessor in the bin-major order, counted per wavefront range of phase 2
+__global__ __launch_bounds__(256) void pb_dupcount_kernel(uint32_t B, uint64_t nnz, const uint32_t* __restrict__ binPos,
+                                                          const uint16_t* __restrict__ lrow, uint32_t* __restrict__ dupCount) {
+    const uint64_t v = lin_block() * 256 + threadIdx.x;
+    if (v == 0 || v >= nnz || lrow[v] != lrow[v - 1]) return;
+    uint32_t lo = 0, hi = B;                        // bin with binPos[bin] <= v < binPos[bin + 1]
+    while (hi - lo > 1) {
+        const uint32_t mid = lo + (hi - lo) / 2;
+        if (binPos[mid] <= v) lo = mid; else hi = mid;
+    }
+    const uint32_t v0 = binPos[lo], v1 = binPos[lo + 1];
+    if (v == v0) return;                            // the predecessor belongs to another bin
+    atomicAdd(&dupCount[(uint64_t)lo * P2_WAVES + (uint32_t)((v - v0) / p2_sub(v1 - v0))], 1u);
 }
 
 #define PB_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { fprintf(stderr, "libspmvhip: tiles: %s: %s\n", #expr, hipGetErrorString(e_)); return EXIT_FAILURE; } } while (0)
@@ -508,6 +575,7 @@ int buildTiles(DevMat* d) {
         PB_TRY(hipMemcpy(&lastIdx, listIdx.as<uint32_t>() + nTiles - 1, 4, hipMemcpyDeviceToHost));
         PB_TRY(hipMemcpy(&lastFlag, flags.as<uint32_t>() + nTiles - 1, 4, hipMemcpyDeviceToHost));
         t->nList = lastIdx + lastFlag;
+        if (t->nList >= P2_RUNS_FLAG) return fail("tile list (more than 2^31 non-empty tiles)");
         if (hipMalloc(&t->tl, ((size_t)t->nList + TL_PAD) * sizeof(uint2))) return fail("tile-list allocation");
         hipLaunchKernelGGL(pb_fill_kernel, dim3(1), dim3(256), 0, nullptr, reinterpret_cast<uint32_t*>(t->tl + t->nList), 2 * TL_PAD, 0xFFFFFFFFu);
         hipLaunchKernelGGL(pb_list_kernel, grid2d((nTiles + 255) / 256, 256), dim3(256), 0, nullptr, t->S, t->B, nnz,
@@ -516,8 +584,13 @@ int buildTiles(DevMat* d) {
         hipLaunchKernelGGL(pb_gather_kernel, grid2d((nnz + 255) / 256, 256), dim3(256), 0, nullptr, nnz, perm.as<uint32_t>(),
                            keysOut.as<uint16_t>(), rowOf.as<uint32_t>(), d->JA, d->AS, t->S, t->B, t->R, tileStart.as<uint32_t>(),
                            bmStart.as<uint32_t>(), t->val, t->lcol, t->lrow);
+        TempBuf dupCount;
+        if (dupCount.alloc((size_t)t->B * P2_WAVES * 4)) return fail("run-count workspace");
+        PB_TRY(hipMemsetAsync(dupCount.p, 0, (size_t)t->B * P2_WAVES * 4, nullptr));
+        hipLaunchKernelGGL(pb_dupcount_kernel, grid2d((nnz + 255) / 256, 256), dim3(256), 0, nullptr, t->B, nnz, t->binPos, t->lrow,
+                           dupCount.as<uint32_t>());
         hipLaunchKernelGGL(pb_wavetile_kernel, grid2d(((uint64_t)t->B * P2_WAVES + 255) / 256, 256), dim3(256), 0, nullptr, t->B,
-                           t->binPos, binTile.as<uint32_t>(), t->tl, t->waveTile);
+                           t->binPos, binTile.as<uint32_t>(), t->tl, dupCount.as<uint32_t>(), t->waveTile);
         PB_TRY(hipGetLastError());
         PB_TRY(hipDeviceSynchronize());
     }
