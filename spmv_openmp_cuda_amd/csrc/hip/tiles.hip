@@ -46,8 +46,11 @@
 
 namespace spmvhip {
 
-constexpr uint32_t PB_C_SHIFT = 14;                 // 16 Ki columns per slice = 128 KiB of x in LDS
-constexpr uint32_t PB_C       = 1u << PB_C_SHIFT;
+#ifndef SPMV_PB_COLS
+#define SPMV_PB_COLS 16384
+#endif
+constexpr uint32_t PB_C       = SPMV_PB_COLS;       // columns per slice: 16 Ki = 128 KiB of x in LDS (19 Ki = 152 KiB measured no faster: c3 1.075 vs 1.050 ms, c5 equal)
+static_assert(PB_C % 1024 == 0 && PB_C * 8 <= 160 * 1024 && PB_C <= 65536, "slice width");
 constexpr uint32_t PB_R_MAX   = 20000;             // rows per bin: <= 156 KiB of y in LDS (160 KiB per CU on gfx950)
 constexpr uint32_t PB_CUS     = 256;               // compute units (phase 2 keeps one workgroup per CU)
 constexpr uint32_t PB_CHUNK   = 1u << 17;           // entries of one slice handled by one phase-1 workgroup
@@ -90,7 +93,7 @@ __global__ __launch_bounds__(256) void pb_keys_kernel(uint64_t nnz, const uint32
                                                       uint16_t* __restrict__ keys, uint32_t* __restrict__ idx) {
     const uint64_t j = lin_block() * 256 + threadIdx.x;
     if (j >= nnz) return;
-    keys[j] = (uint16_t)(JA[j] >> PB_C_SHIFT);
+    keys[j] = (uint16_t)(JA[j] / PB_C);
     idx[j] = (uint32_t)j;
 }
 
@@ -151,7 +154,7 @@ __global__ __launch_bounds__(256) void pb_gather_kernel(
     const uint32_t j = perm[p];
     const uint32_t row = rowOf[j], bin = row / R, slice = skeys[p];
     val[p] = AS[j];
-    lcol[p] = (uint16_t)(JA[j] & (PB_C - 1));
+    lcol[p] = (uint16_t)(JA[j] % PB_C);
     const uint32_t within = (uint32_t)p - tileStart[(uint64_t)slice * B + bin];
     lrow[bmStart[(uint64_t)bin * S + slice] + within] = (uint16_t)(row - bin * R);
 }
@@ -220,7 +223,7 @@ __global__ __launch_bounds__(PB_THREADS) void pb_expand_kernel(
     P1Regs cur, nxt;
     if (vec) p1_load(cur, p, ve, val, lcol);        // the stream starts moving before the x slice is staged
 
-    const uint64_t col0 = (uint64_t)w.x << PB_C_SHIFT;
+    const uint64_t col0 = (uint64_t)w.x * PB_C;
     {
         double xv[PB_C / PB_THREADS];
 #pragma unroll
@@ -499,7 +502,7 @@ int buildTiles(DevMat* d) {
     if (d->kind != Kind::CSR) return EXIT_FAILURE;
     const uint64_t nnz = d->NZ, M = d->M, N = d->N;
     if (nnz >= IRP32_LIMIT || nnz == 0) { fprintf(stderr, "libspmvhip: tiles: nnz = %lu unsupported (needs 0 < nnz < 2^32)\n", (unsigned long)nnz); return EXIT_FAILURE; }
-    const uint64_t S64 = (N + PB_C - 1) >> PB_C_SHIFT;
+    const uint64_t S64 = (N + PB_C - 1) / PB_C;
     if (S64 > 65535) { fprintf(stderr, "libspmvhip: tiles: %lu columns exceed 65535 slices\n", (unsigned long)N); return EXIT_FAILURE; }
     TileFormat* t = new TileFormat;
     t->S = (uint32_t)S64;
