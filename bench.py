@@ -53,10 +53,14 @@ def parse():
     p.add_argument("--cpu-sample-nnz", type=int, default=100_000_000)
     p.add_argument("--groups", type=int, default=0,
                    help="row groups per rank for kernel/all-gather overlap at N > 1 (0 = measure 1/2[/4] and keep the fastest)")
-    p.add_argument("--exchange", default="auto", choices=["auto", "rccl", "push", "fused"],
+    p.add_argument("--exchange", default="auto", choices=["auto", "rccl", "push", "fused", "auto-no-rccl"],
                    help="how y reaches the other ranks at N > 1: RCCL all-gather, copy-engine pushes into peer windows, or "
                         "stores fused into phase 2 of the two-phase kernel (auto = measure all, keep the fastest)")
     p.add_argument("--pieces", type=int, default=0, help="pieces of y per rank for --exchange push (0 = measure 1/2/4/8)")
+    p.add_argument("--rehearse-shared-gpu", action="store_true",
+                   help="development only: all ranks use GPU 0 and gloo is the control plane (RCCL refuses two ranks on one "
+                        "device), so the N > 1 code path -- plan, candidates, peer windows, checks -- can run on a one-GPU "
+                        "box; the RCCL all-gather candidates are skipped and the timings mean nothing")
     p.add_argument("--force-dist", action="store_true",
                    help="run the multi-rank code path (process group, all-gather) even with --gpus 1; for rehearsal")
     return p.parse_args()
@@ -328,8 +332,15 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29531")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
-        torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if args.rehearse_shared_gpu:
+            local = 0
+            torch.cuda.set_device(0)
+            dist.init_process_group("gloo")
+            if args.exchange in ("auto", "rccl"):
+                args.exchange = "auto-no-rccl"
+        else:
+            torch.cuda.set_device(local)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
     else:
         torch.cuda.set_device(0)
     if world > 1:                                    # host-side generators are OpenMP: share the cores between the ranks
@@ -493,7 +504,7 @@ def main():
     # push exchange over peer windows with 1..8 pieces, and the fused store.  Whole steps, slowest rank, 3 steps each;
     # a candidate whose y differs from the first candidate's is dropped.
     px = None
-    if args.exchange in ("auto", "push", "fused"):
+    if args.exchange in ("auto", "auto-no-rccl", "push", "fused"):
         px = sharding.PeerExchange(api, dist, torch, rank, world, local, w.N)
         if not px.ok:
             log("peer windows unavailable, RCCL only:", px.why)
@@ -502,11 +513,11 @@ def main():
         if args.exchange in ("auto", "rccl"):
             for G in ([args.groups] if args.groups > 0 else ([1, 2, 4] if world == 2 else [1, 2])):
                 yield (lambda G=G: first if G == 1 else RcclExchange(G))
-        if px is not None and args.exchange in ("auto", "push"):
+        if px is not None and args.exchange in ("auto", "auto-no-rccl", "push"):
             for q in ([args.pieces] if args.pieces > 0 else ([1, 2, 4, 8] if launcher == "hipSpMVTilesCSR" else [1])):
                 yield (lambda q=q: PushExchange(px, base_dm, "push", q))
         # the fused store is tried only after a copy-engine push through the same mappings delivered a correct y
-        if px is not None and args.exchange in ("auto", "fused") and launcher == "hipSpMVTilesCSR" and \
+        if px is not None and args.exchange in ("auto", "auto-no-rccl", "fused") and launcher == "hipSpMVTilesCSR" and \
                 (args.exchange == "fused" or any(k.startswith("push") for k in exchange_ms)):
             yield (lambda: PushExchange(px, base_dm, "fused", 1))
     exchange_ms, rejected = {}, {}
