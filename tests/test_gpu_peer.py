@@ -130,3 +130,25 @@ def test_tiles_reduce_bin_ranges_single_process():
     assert api.lib.hipSpMVTilesReduce(C.byref(dm.handle), 2, 1, dy.ptr, 0, None) == 1
     assert api.lib.hipSpMVTilesReduce(C.byref(dm.handle), 0, nb.value + 1, dy.ptr, 0, None) == 1
     dm.free()
+
+
+@pytest.mark.parametrize("world,launcher", [(2, "auto"), (3, "hipSpMVWarpPerRowCSR")])
+def test_bench_multirank_path_on_shared_gpu(world, launcher):
+    """bench.py's N > 1 code end to end (plan, kernel pick + broadcast, exchange candidates through peer windows,
+    cross-rank and oracle checks, the ONE JSON line) with `world` ranks sharing the GPU; timings mean nothing."""
+    import json
+    import subprocess
+    port = _free_port()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--rehearse-shared-gpu",
+           "--workload", "c3", "--scale", "0.05", "--steps", "3", "--warmup", "1", "--launcher", launcher]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, r.stdout                      # exactly one JSON line on stdout
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == world and j["parity"]["ok"] and j["parity"]["all_ranks_hold_identical_y"]
+    assert j["config"]["exchange"] in j["config"]["exchange_step_ms"] and not j["config"]["exchange_rejected"]
+    assert any(k.startswith("push") for k in j["config"]["exchange_step_ms"])
+    if launcher == "auto":
+        assert "fused" in j["config"]["exchange_step_ms"] or j["config"]["kernel"] != "hipSpMVTilesCSR"
