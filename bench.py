@@ -559,6 +559,30 @@ def main():
         torch.cuda.empty_cache()
     if best is None:
         raise SystemExit(f"no exchange candidate produced a complete y: {rejected}")
+
+    # the exchange alone (no kernels), for the record: what the links give an all-gather of y at this N
+    def alone(fn_once, reps=5):
+        fn_once()
+        dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn_once()
+        torch.cuda.synchronize()
+        tt = torch.tensor([(time.perf_counter() - t0) / reps * 1e3], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        return float(tt[0])
+    exchange_alone_ms = {}
+    if not args.rehearse_shared_gpu and first.bufs is not None:
+        exchange_alone_ms["rccl_all_gather"] = alone(lambda: dist.all_gather_into_tensor(first.bufs.ypad[0], first.bufs.slot[0]))
+    if px is not None:
+        r0_, r1_ = base_plan.rows(rank)
+        def push_once():
+            px.push(r0_, r1_)
+            px.finish()
+        exchange_alone_ms["push_copy_engines"] = alone(push_once)
+        exchange_alone_ms["barrier_only"] = alone(lambda: px.finish())
+    log("exchange alone (ms, slowest rank):", exchange_alone_ms)
     setup = best
     log("exchange candidates (ms/step, slowest rank):", exchange_ms, "rejected:", rejected, "->", setup.name)
     groups, plan = setup.events, setup.plan
@@ -596,7 +620,8 @@ def main():
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": info["workload"], **{k: v for k, v in info.items() if k != "workload"},
                        "kernel": launcher, "auto_candidates_ms": tried, "exchange": setup.name,
-                       "exchange_step_ms": exchange_ms, "exchange_rejected": rejected, "parallelism": setup.desc},
+                       "exchange_step_ms": exchange_ms, "exchange_rejected": rejected,
+                       "exchange_alone_ms": exchange_alone_ms, "parallelism": setup.desc},
             "hbm_gbps": bytes_alg_total / (wall_max / steps) * 1e-9,
             "hbm_roofline_frac": bytes_alg_total / (wall_max / steps) / (HBM_PEAK * world),
             "roofline": {"bound": "hbm", "achieved": bytes_alg_local / k_avg * 1e-9, "peak": HBM_PEAK * 1e-9,
