@@ -471,11 +471,12 @@ def main():
             self.events = 1
             self.plan = base_plan
             self.run = sharding.PushSpMV(api, px, dm, base_plan.rows(rank)[0], launcher, x.data_ptr(), mode, pieces)
-            self.name = "fused" if mode == "fused" else f"push-p{self.run.pieces}"
+            self.name = mode if mode in ("fused", "pushk") else f"push-p{self.run.pieces}"
             self.y = px.y
             self.groups = 1
             self.desc = (f"{world} ranks, one nnz-balanced row block each, y in peer windows (device IPC over xGMI): " +
                          ("phase 2 stores every finished bin of y to all ranks itself" if mode == "fused" else
+                          "a push kernel beside phase 2 copies every bin of y to all ranks as soon as it is flagged" if mode == "pushk" else
                           f"{self.run.pieces} piece(s) of y, each pushed to all ranks by the copy engines while the next is reduced") +
                          "; step ends with a 4-byte RCCL all-reduce as barrier")
 
@@ -520,6 +521,8 @@ def main():
         if px is not None and args.exchange in ("auto", "auto-no-rccl", "fused") and launcher == "hipSpMVTilesCSR" and \
                 (args.exchange == "fused" or any(k.startswith("push") for k in exchange_ms)):
             yield (lambda: PushExchange(px, base_dm, "fused", 1))
+            if world > 1:
+                yield (lambda: PushExchange(px, base_dm, "pushk", 1))
     exchange_ms, rejected = {}, {}
     best, ref_sum = None, None
     for make in candidates():

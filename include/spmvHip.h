@@ -217,6 +217,13 @@ int spmvHipPeerPushJoin(void);
 int spmvHipTilesShape(spmat* dMat, unsigned* nBins, unsigned* rowsPerBin);
 int hipSpMVTilesExpand(spmat* dMat, double* dX);
 int hipSpMVTilesReduce(spmat* dMat, unsigned binBegin, unsigned binEnd, double* dY, int nExtra, double* const* dExtra);
+/* Phase 2 over all bins with a PUSH KERNEL beside it (own high-priority stream, no LDS, a few wavefronts per CU):
+ * every reduction workgroup sets a per-bin flag when its rows of y are stored (agent-scope release), the push
+ * kernel copies each flagged bin to the nExtra destinations.  The reduction never waits for a link and the links
+ * work from the first finished bin on.  The library stream continues after both kernels.  A flag that does not
+ * arrive within ~2 s makes the push kernel give up (spmvHipTilesPushFailed() == 1, y incomplete) rather than hang. */
+int hipSpMVTilesReducePush(spmat* dMat, double* dY, int nExtra, double* const* dExtra);
+int spmvHipTilesPushFailed(spmat* dMat);
 
 /* ------------------------------------------------- synthetic matrices on device */
 /* Fill JA/AS of a CSR whose row pointers are given (device arrays, device

@@ -78,6 +78,7 @@ _sigs = {
     "spmvHipTilesShape": ([C.POINTER(spmat), C.POINTER(C.c_uint), C.POINTER(C.c_uint)], _i),
     "hipSpMVTilesExpand": ([C.POINTER(spmat), _vp], _i),
     "hipSpMVTilesReduce": ([C.POINTER(spmat), C.c_uint, C.c_uint, _vp, _i, _vp], _i),
+    "hipSpMVTilesReducePush": ([C.POINTER(spmat), _vp, _i, _vp], _i), "spmvHipTilesPushFailed": ([C.POINTER(spmat)], _i),
 }
 IPC_HANDLE_BYTES = 64
 MAX_PEERS = 15

@@ -676,6 +676,31 @@ int hipSpMVTilesReduce(spmat* dMat, unsigned binBegin, unsigned binEnd, double* 
     return L.finish("hipSpMVTilesReduce");
 }
 
+int hipSpMVTilesReducePush(spmat* dMat, double* dY, int nExtra, double* const* dExtra) {
+    DevMat* d = tilesReady(dMat, "hipSpMVTilesReducePush");
+    if (!d) return EXIT_FAILURE;
+    if (nExtra < 1 || nExtra > SPMV_MAX_PEERS || !dExtra || !dY) { ERR("hipSpMVTilesReducePush: %d destinations: invalid", nExtra); return EXIT_FAILURE; }
+    static hipStream_t side = nullptr;
+    static hipEvent_t evFork = nullptr, evJoin = nullptr;
+    if (!side) {
+        int lo = 0, hi = 0;
+        HIP_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));
+        HIP_TRY(hipStreamCreateWithPriority(&side, hipStreamNonBlocking, hi));      // dispatched ahead of phase 2's later rounds
+        HIP_TRY(hipEventCreateWithFlags(&evFork, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&evJoin, hipEventDisableTiming));
+    }
+    uint32_t b = 0, r = 0;
+    tilesShape(d, &b, &r);
+    Launch L(dim3(b), dim3(1024));
+    if (enqueueTilesReducePush(d, dY, nExtra, dExtra, S.stream, side, evFork, evJoin)) { ERR("hipSpMVTilesReducePush: launch failed"); return EXIT_FAILURE; }
+    return L.finish("hipSpMVTilesReducePush");
+}
+
+int spmvHipTilesPushFailed(spmat* dMat) {
+    DevMat* d = descOf(dMat, "spmvHipTilesPushFailed");
+    return d ? tilesPushFailed(d) : 1;
+}
+
 int hipSpMVRowsELL(spmat* dMat, double* dX, CONFIG cfg, double* dY) {
     DevMat* d = descOf(dMat, "hipSpMVRowsELL");
     if (!d) return EXIT_FAILURE;

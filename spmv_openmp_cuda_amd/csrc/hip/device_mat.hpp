@@ -70,6 +70,9 @@ void freeTilesWorkspace();                                      // the per-devic
 int  enqueueTiles(DevMat* d, const double* x, double* y, hipStream_t stream);
 int  enqueueTilesExpand(DevMat* d, const double* x, hipStream_t stream);
 int  enqueueTilesReduce(DevMat* d, uint32_t binBegin, uint32_t binEnd, double* y, int nExtra, double* const* extra, hipStream_t stream);
+int  enqueueTilesReducePush(DevMat* d, double* y, int nExtra, double* const* extra, hipStream_t stream, hipStream_t side,
+                            hipEvent_t evFork, hipEvent_t evJoin);
+int  tilesPushFailed(DevMat* d);
 void tilesShape(const DevMat* d, uint32_t* bins, uint32_t* rowsPerBin);
 hipStream_t libraryStream();                                    // abi.hip: the stream set with spmvHipSetStream
 size_t tilesBytes(const DevMat* d);

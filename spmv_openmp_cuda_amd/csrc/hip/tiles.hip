@@ -71,10 +71,14 @@ struct TileFormat {
     uint3*    work = nullptr;                       // phase-1 work items {slice, begin, end}
     uint32_t  nWork = 0;
     bool      ntStore = true;                       // phase 1 stores the products non-temporally (streams larger than the Infinity Cache)
+    uint32_t* ready = nullptr;                      // [B] epoch of the last step whose bin was stored (push kernel hand-off)
+    uint32_t* pushFail = nullptr;                   // set by the push kernel when a flag never arrived
+    uint32_t  epoch = 0;
     size_t    bytes = 0;
 };
 
 struct TileDst { double* p[SPMV_MAX_PEERS]; uint32_t n; };
+struct TileSignal { uint32_t* ready; uint32_t epoch; };        // per-bin "this bin of y is stored" flags (push kernel)
 
 namespace {
 
@@ -339,11 +343,11 @@ __device__ __forceinline__ void p2_add_runs(double* yb, uint16_t rv, double pv, 
 // MULTI: the finished bin of y is also stored to `extra.n` further destinations -- the copies of y that the other
 // ranks of a multi-GPU run hold, mapped into this process (peer windows over xGMI, peer.hip): the all-gather of y
 // is fused into the producing kernel as point-to-point stores, one 512-B run per wavefront instruction.
-template <bool MULTI>
+template <int MODE>                                 // 0: y only; 1: y + extra destinations; 2: y + per-bin ready flag
 __global__ __launch_bounds__(PB_THREADS) void pb_reduce_kernel(
     uint32_t R, uint32_t binBegin, uint32_t binEnd, uint64_t M, const uint32_t* __restrict__ binPos, const uint32_t* __restrict__ waveTile,
     const uint2* __restrict__ tl, const double* __restrict__ prod, const uint16_t* __restrict__ lrow,
-    double* __restrict__ y, TileDst extra) {
+    double* __restrict__ y, TileDst extra, TileSignal sig) {
     extern __shared__ double yb[];                  // R doubles
 #ifdef SPMV_P2_XCD      // tuning: give every XCD a contiguous range of bins (workgroups are dealt round-robin to the 8 XCDs)
     const uint32_t nBins = binEnd - binBegin;
@@ -403,7 +407,7 @@ __global__ __launch_bounds__(PB_THREADS) void pb_reduce_kernel(
     const uint64_t r0 = bin * R;
     for (uint32_t k = threadIdx.x; k < R; k += PB_THREADS)
         if (r0 + k < M) y[r0 + k] = yb[k];
-    if (MULTI) {
+    if (MODE == 1) {
         // destination-major (long contiguous runs per link); workgroups start at different destinations so that
         // all links carry traffic all the time
         for (uint32_t i = 0; i < extra.n; ++i) {
@@ -411,6 +415,60 @@ __global__ __launch_bounds__(PB_THREADS) void pb_reduce_kernel(
             for (uint32_t k = threadIdx.x; k < R; k += PB_THREADS)
                 if (r0 + k < M) dst[r0 + k] = yb[k];
         }
+    }
+    if (MODE == 2) {
+        // hand the finished bin to the push kernel (another CU, maybe another XCD): every storing wave waits for its
+        // stores, the workgroup meets, ONE lane writes the XCD's L2 back (agent release) and only then sets the flag
+        // (MI355X_MICROARCH.md "inter-workgroup visibility", producer form; the explicit wait after the fence is the
+        // documented guard against the compiler dropping it)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __hip_atomic_store(sig.ready + bin, sig.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
+// The push kernel: runs BESIDE phase 2 (own stream, a few wavefronts per CU, no LDS -- phase 2 leaves wave slots free)
+// and copies every bin of y to the other ranks' vectors as soon as its flag shows this step's epoch.  Workgroup w serves
+// peer w % n and the bins k, k + perPeer, ... (k = w / n) in ascending order, the order phase 2 produces them in.  Unlike
+// the fused store the reduction workgroups never wait for a link, and the links start working after the first round of
+// bins instead of in bursts at the end of every round.  A flag that does not arrive within ~2 s marks the step failed
+// (the caller then sees an incomplete y) instead of hanging the GPU.
+typedef double dbl2_t __attribute__((ext_vector_type(2)));
+constexpr int      PUSH_THREADS = 256;
+constexpr uint32_t PUSH_SPIN_LIMIT = 1u << 20;
+__global__ __launch_bounds__(PUSH_THREADS) void pb_push_kernel(
+    uint32_t R, uint32_t B, uint64_t M, const uint32_t* __restrict__ ready, uint32_t epoch, const double* __restrict__ y,
+    TileDst dst, uint32_t perPeer, uint32_t* __restrict__ fail) {
+    __shared__ uint32_t ok;
+    const uint32_t peer = blockIdx.x % dst.n, k0 = blockIdx.x / dst.n;
+    double* __restrict__ out = dst.p[peer];
+    for (uint32_t bin = k0; bin < B; bin += perPeer) {
+        if (threadIdx.x == 0) {
+            uint32_t spins = 0, seen;
+            while ((seen = __hip_atomic_load(ready + bin, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) != epoch && ++spins < PUSH_SPIN_LIMIT)
+                __builtin_amdgcn_s_sleep(64);
+            ok = seen == epoch;
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");          // consumer form: one poll, one acquire, wait, barrier
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __syncthreads();
+        if (!ok) { if (threadIdx.x == 0) atomicExch(fail, 1u); return; }
+        const uint64_t r0 = (uint64_t)bin * R, r1 = min(r0 + R, M);
+        // 16-byte accesses; y and out share their alignment (same row offset from 256-B aligned bases): peel one row
+        // when the rank's first row is odd
+        const uint64_t head = ((uintptr_t)(y + r0) & 15) ? 1 : 0;
+        const uint64_t pairs = (r1 - r0 - head) / 2;
+        for (uint64_t i = threadIdx.x; i < pairs; i += PUSH_THREADS)
+            *(dbl2_t*)(out + r0 + head + 2 * i) = *(const dbl2_t*)(y + r0 + head + 2 * i);
+        if (threadIdx.x == 0) {
+            if (head && r1 > r0) out[r0] = y[r0];
+            if ((r1 - r0 - head) & 1) out[r1 - 1] = y[r1 - 1];
+        }
+        __syncthreads();                            // `ok` is rewritten in the next round
     }
 }
 
@@ -493,7 +551,7 @@ void freeTilesWorkspace() {
 void freeTiles(TileFormat* t) {
     if (!t) return;
     (void)hipFree(t->val); (void)hipFree(t->lcol); (void)hipFree(t->lrow); (void)hipFree(t->tl);
-    (void)hipFree(t->binPos); (void)hipFree(t->waveTile); (void)hipFree(t->work);
+    (void)hipFree(t->binPos); (void)hipFree(t->waveTile); (void)hipFree(t->work); (void)hipFree(t->ready);
     delete t;
 }
 
@@ -649,8 +707,9 @@ int buildTiles(DevMat* d) {
     if (!attrSet) {
         PB_TRY(hipFuncSetAttribute((const void*)pb_expand_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, PB_C * 8));
         PB_TRY(hipFuncSetAttribute((const void*)pb_expand_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, PB_C * 8));
-        PB_TRY(hipFuncSetAttribute((const void*)pb_reduce_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, PB_R_MAX * 8));
-        PB_TRY(hipFuncSetAttribute((const void*)pb_reduce_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, PB_R_MAX * 8));
+        PB_TRY(hipFuncSetAttribute((const void*)pb_reduce_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, PB_R_MAX * 8));
+        PB_TRY(hipFuncSetAttribute((const void*)pb_reduce_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, PB_R_MAX * 8));
+        PB_TRY(hipFuncSetAttribute((const void*)pb_reduce_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, PB_R_MAX * 8));
         attrSet = true;
     }
     // products that fit the Infinity Cache (with room for x and the streams) are stored with the default policy so
@@ -698,13 +757,51 @@ int enqueueTilesReduce(DevMat* d, uint32_t binBegin, uint32_t binEnd, double* y,
     TileDst dst{};
     dst.n = (uint32_t)nExtra;
     for (int i = 0; i < nExtra; ++i) dst.p[i] = extra[i];
+    const TileSignal none{nullptr, 0};
     if (nExtra)
-        hipLaunchKernelGGL(pb_reduce_kernel<true>, grid, dim3(PB_THREADS), (size_t)8 * t->R, stream,
-                           t->R, binBegin, binEnd, d->M, t->binPos, t->waveTile, t->tl, prod, t->lrow, y, dst);
+        hipLaunchKernelGGL(pb_reduce_kernel<1>, grid, dim3(PB_THREADS), (size_t)8 * t->R, stream,
+                           t->R, binBegin, binEnd, d->M, t->binPos, t->waveTile, t->tl, prod, t->lrow, y, dst, none);
     else
-        hipLaunchKernelGGL(pb_reduce_kernel<false>, grid, dim3(PB_THREADS), (size_t)8 * t->R, stream,
-                           t->R, binBegin, binEnd, d->M, t->binPos, t->waveTile, t->tl, prod, t->lrow, y, dst);
+        hipLaunchKernelGGL(pb_reduce_kernel<0>, grid, dim3(PB_THREADS), (size_t)8 * t->R, stream,
+                           t->R, binBegin, binEnd, d->M, t->binPos, t->waveTile, t->tl, prod, t->lrow, y, dst, none);
     return hipGetLastError() == hipSuccess ? EXIT_SUCCESS : EXIT_FAILURE;
+}
+
+// phase 2 over all bins on `stream` with the push kernel beside it on `side`: `side` first waits for what is enqueued on
+// `stream` so far (phase 1), `stream` finally waits for the push kernel.  y and the nExtra destinations as above.
+int enqueueTilesReducePush(DevMat* d, double* y, int nExtra, double* const* extra, hipStream_t stream, hipStream_t side,
+                           hipEvent_t evFork, hipEvent_t evJoin) {
+    TileFormat* t = d->tiles;
+    if (!t || nExtra < 1 || nExtra > SPMV_MAX_PEERS) return EXIT_FAILURE;
+    const double* prod = prodWorkspace(t->nnz, true);
+    if (!prod) return EXIT_FAILURE;
+    if (!t->ready) {
+        if (hipMalloc(&t->ready, ((size_t)t->B + 1) * 4) != hipSuccess) return EXIT_FAILURE;
+        if (hipMemset(t->ready, 0, ((size_t)t->B + 1) * 4) != hipSuccess) return EXIT_FAILURE;   // [B] doubles as the failure word
+        t->pushFail = t->ready + t->B;
+    }
+    const uint32_t epoch = ++t->epoch ? t->epoch : ++t->epoch;             // never 0 (the initial flag value)
+    TileDst dst{};
+    dst.n = (uint32_t)nExtra;
+    for (int i = 0; i < nExtra; ++i) dst.p[i] = extra[i];
+    const TileSignal sig{t->ready, epoch};
+    const uint32_t perPeer = std::min<uint32_t>(8, t->B);
+    if (hipEventRecord(evFork, stream) != hipSuccess || hipStreamWaitEvent(side, evFork, 0) != hipSuccess) return EXIT_FAILURE;
+    hipLaunchKernelGGL(pb_push_kernel, dim3(perPeer * dst.n), dim3(PUSH_THREADS), 0, side, t->R, t->B, d->M, t->ready, epoch, y, dst,
+                       perPeer, t->pushFail);
+    hipLaunchKernelGGL(pb_reduce_kernel<2>, grid2d((uint64_t)((t->B + 7) / 8) * 8, PB_THREADS), dim3(PB_THREADS), (size_t)8 * t->R, stream,
+                       t->R, 0u, t->B, d->M, t->binPos, t->waveTile, t->tl, prod, t->lrow, y, TileDst{}, sig);
+    if (hipEventRecord(evJoin, side) != hipSuccess || hipStreamWaitEvent(stream, evJoin, 0) != hipSuccess) return EXIT_FAILURE;
+    return hipGetLastError() == hipSuccess ? EXIT_SUCCESS : EXIT_FAILURE;
+}
+
+// 1 when a push kernel of this matrix ever gave up waiting for a bin (synchronises the device)
+int tilesPushFailed(DevMat* d) {
+    TileFormat* t = d->tiles;
+    if (!t || !t->pushFail) return 0;
+    uint32_t f = 0;
+    if (hipMemcpy(&f, t->pushFail, 4, hipMemcpyDeviceToHost) != hipSuccess) return 1;
+    return f != 0;
 }
 
 // enqueue both phases on `stream`

@@ -234,7 +234,9 @@ class PushSpMV:
     mode "push":  kernel pieces -> copy-engine pushes behind each piece (tiles launcher: phase 1 once, phase 2 cut
                   into `pieces` bin ranges so that the push of one range travels under the reduction of the next;
                   other launchers: one piece);
-    mode "fused": hipSpMVTilesReduce stores every finished bin to all the peers itself (tiles launcher only)."""
+    mode "fused": hipSpMVTilesReduce stores every finished bin to all the peers itself (tiles launcher only);
+    mode "pushk": hipSpMVTilesReducePush -- a push kernel beside phase 2 copies every bin to the peers as soon as the
+                  reduction flags it (tiles launcher only, needs at least one peer)."""
 
     def __init__(self, api, px, dm, row0, launcher, x_ptr, mode="push", pieces=1, barrier=None, unit=256):
         import ctypes as C
@@ -244,8 +246,8 @@ class PushSpMV:
         self.rows = int(dm.rows)
         self.y_own = C.c_void_p(px.base.value + 8 * self.row0)
         self.tiles = launcher == "hipSpMVTilesCSR" and self.rows > 0 and int(dm.nnz) > 0
-        if mode == "fused" and not self.tiles:
-            raise ValueError("the fused exchange exists for hipSpMVTilesCSR only")
+        if mode in ("fused", "pushk") and not self.tiles:
+            raise ValueError("the fused / push-kernel exchange exists for hipSpMVTilesCSR only")
         if self.tiles:
             nb, rpb = C.c_uint(), C.c_uint()
             if api.lib.spmvHipTilesShape(C.byref(dm.handle), C.byref(nb), C.byref(rpb)):
@@ -265,6 +267,8 @@ class PushSpMV:
             if self.mode == "fused":
                 b0, b1 = self.ranges[0][0], self.ranges[-1][1]
                 rc = rc or lib.hipSpMVTilesReduce(h, b0, b1, self.y_own, self.n_extra, self.extra)
+            elif self.mode == "pushk":
+                rc = rc or lib.hipSpMVTilesReducePush(h, self.y_own, self.n_extra, self.extra)
             else:
                 for b0, b1 in self.ranges:
                     rc = rc or lib.hipSpMVTilesReduce(h, b0, b1, self.y_own, 0, None)

@@ -60,16 +60,20 @@ def _worker(rank, world, port, out_dir):
         verdict.append("setup: " + px.why)
     cases = [("hipSpMVRowsCSR", "push", 1, True), ("hipSpMVWarpPerRowCSR", "push", 1, False),
              ("hipSpMVTilesCSR", "push", 1, False), ("hipSpMVTilesCSR", "push", 3, False),
-             ("hipSpMVTilesCSR", "fused", 1, False)]
+             ("hipSpMVTilesCSR", "fused", 1, False), ("hipSpMVTilesCSR", "pushk", 1, False)]
     for launcher, mode, pieces, exact in (cases if ok else []):
         run = sharding.PushSpMV(api, px, dm, r0, launcher, x.data_ptr(), mode, pieces, barrier=host_barrier, unit=4)
         px.y.fill_(float("nan"))
         host_barrier()
-        for _ in range(2):                               # two steps: the windows are re-used
+        for _ in range(6 if mode == "pushk" else 2):     # several steps: windows and flags are re-used, consumer L1 warm
             y = run.step()
+        if mode == "pushk":
+            good_push = api.lib.spmvHipTilesPushFailed(C.byref(dm.handle)) == 0
+        else:
+            good_push = True
         host_barrier()
         yh = y.cpu().numpy()
-        good = not np.isnan(yh).any()
+        good = good_push and not np.isnan(yh).any()
         good = good and (np.array_equal(yh, y_ref) if exact else bool(np.all(np.abs(yh - y_ref) <= 1e-13 * scale + 1e-300)))
         sums = [None] * world
         dist.all_gather_object(sums, yh.tobytes() if w.N < 1_000_000 else float(yh.sum()))
