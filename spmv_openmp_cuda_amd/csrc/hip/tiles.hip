@@ -432,21 +432,27 @@ __global__ __launch_bounds__(PB_THREADS) void pb_reduce_kernel(
 }
 
 // The push kernel: runs BESIDE phase 2 (own stream, a few wavefronts per CU, no LDS -- phase 2 leaves wave slots free)
-// and copies every bin of y to the other ranks' vectors as soon as its flag shows this step's epoch.  Workgroup w serves
-// peer w % n and the bins k, k + perPeer, ... (k = w / n) in ascending order, the order phase 2 produces them in.  Unlike
-// the fused store the reduction workgroups never wait for a link, and the links start working after the first round of
-// bins instead of in bursts at the end of every round.  A flag that does not arrive within ~2 s marks the step failed
-// (the caller then sees an incomplete y) instead of hanging the GPU.
+// and copies every bin of y to the other ranks' vectors as soon as its flag shows this step's epoch.  Workgroup w takes
+// the bins w, w + W, ... in ascending order (the order phase 2 produces them in) and serves ALL peers from one read of
+// the bin: per lane PUSH_DEPTH 16-byte loads, then those registers stored to every peer (posted stores: with a link
+// hop of microseconds what counts is bytes in flight -- a first version with one peer per workgroup and one load per
+// store moved 9 GB/s per workgroup under phase 2's memory load).  Unlike the fused store the reduction workgroups never
+// wait for a link, and the links work from the first finished bin on instead of in bursts at the end of every round of
+// bins.  A flag that does not arrive within ~2 s marks the step failed (the caller then sees an incomplete y) instead
+// of hanging the GPU.
 typedef double dbl2_t __attribute__((ext_vector_type(2)));
 constexpr int      PUSH_THREADS = 256;
+constexpr int      PUSH_DEPTH = 8;
+#ifndef SPMV_PUSH_WGS
+#define SPMV_PUSH_WGS 64
+#endif
+constexpr uint32_t PUSH_WGS = SPMV_PUSH_WGS;
 constexpr uint32_t PUSH_SPIN_LIMIT = 1u << 20;
 __global__ __launch_bounds__(PUSH_THREADS) void pb_push_kernel(
     uint32_t R, uint32_t B, uint64_t M, const uint32_t* __restrict__ ready, uint32_t epoch, const double* __restrict__ y,
-    TileDst dst, uint32_t perPeer, uint32_t* __restrict__ fail) {
+    TileDst dst, uint32_t* __restrict__ fail) {
     __shared__ uint32_t ok;
-    const uint32_t peer = blockIdx.x % dst.n, k0 = blockIdx.x / dst.n;
-    double* __restrict__ out = dst.p[peer];
-    for (uint32_t bin = k0; bin < B; bin += perPeer) {
+    for (uint32_t bin = blockIdx.x; bin < B; bin += gridDim.x) {
         if (threadIdx.x == 0) {
             uint32_t spins = 0, seen;
             while ((seen = __hip_atomic_load(ready + bin, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) != epoch && ++spins < PUSH_SPIN_LIMIT)
@@ -458,13 +464,29 @@ __global__ __launch_bounds__(PUSH_THREADS) void pb_push_kernel(
         __syncthreads();
         if (!ok) { if (threadIdx.x == 0) atomicExch(fail, 1u); return; }
         const uint64_t r0 = (uint64_t)bin * R, r1 = min(r0 + R, M);
-        // 16-byte accesses; y and out share their alignment (same row offset from 256-B aligned bases): peel one row
-        // when the rank's first row is odd
+        // 16-byte accesses; y and the peers' vectors share their alignment (same row offset from 256-B aligned bases):
+        // peel one row when the rank's first row is odd
         const uint64_t head = ((uintptr_t)(y + r0) & 15) ? 1 : 0;
         const uint64_t pairs = (r1 - r0 - head) / 2;
-        for (uint64_t i = threadIdx.x; i < pairs; i += PUSH_THREADS)
-            *(dbl2_t*)(out + r0 + head + 2 * i) = *(const dbl2_t*)(y + r0 + head + 2 * i);
-        if (threadIdx.x == 0) {
+        const double* __restrict__ src = y + r0 + head;
+        for (uint64_t i = threadIdx.x; i < pairs; i += (uint64_t)PUSH_THREADS * PUSH_DEPTH) {
+            dbl2_t v[PUSH_DEPTH];
+#pragma unroll
+            for (int u = 0; u < PUSH_DEPTH; ++u) {
+                const uint64_t q = i + (uint64_t)u * PUSH_THREADS;
+                v[u] = *(const dbl2_t*)(src + 2 * (q < pairs ? q : i));
+            }
+            for (uint32_t k = 0; k < dst.n; ++k) {                      // peers in a bin-dependent order: all links busy
+                double* __restrict__ out = dst.p[(k + bin) % dst.n] + r0 + head;
+#pragma unroll
+                for (int u = 0; u < PUSH_DEPTH; ++u) {
+                    const uint64_t q = i + (uint64_t)u * PUSH_THREADS;
+                    if (q < pairs) *(dbl2_t*)(out + 2 * q) = v[u];
+                }
+            }
+        }
+        if (threadIdx.x < dst.n) {
+            double* __restrict__ out = dst.p[threadIdx.x];
             if (head && r1 > r0) out[r0] = y[r0];
             if ((r1 - r0 - head) & 1) out[r1 - 1] = y[r1 - 1];
         }
@@ -785,10 +807,9 @@ int enqueueTilesReducePush(DevMat* d, double* y, int nExtra, double* const* extr
     dst.n = (uint32_t)nExtra;
     for (int i = 0; i < nExtra; ++i) dst.p[i] = extra[i];
     const TileSignal sig{t->ready, epoch};
-    const uint32_t perPeer = std::min<uint32_t>(8, t->B);
     if (hipEventRecord(evFork, stream) != hipSuccess || hipStreamWaitEvent(side, evFork, 0) != hipSuccess) return EXIT_FAILURE;
-    hipLaunchKernelGGL(pb_push_kernel, dim3(perPeer * dst.n), dim3(PUSH_THREADS), 0, side, t->R, t->B, d->M, t->ready, epoch, y, dst,
-                       perPeer, t->pushFail);
+    hipLaunchKernelGGL(pb_push_kernel, dim3(std::min<uint32_t>(PUSH_WGS, t->B)), dim3(PUSH_THREADS), 0, side, t->R, t->B, d->M, t->ready,
+                       epoch, y, dst, t->pushFail);
     hipLaunchKernelGGL(pb_reduce_kernel<2>, grid2d((uint64_t)((t->B + 7) / 8) * 8, PB_THREADS), dim3(PB_THREADS), (size_t)8 * t->R, stream,
                        t->R, 0u, t->B, d->M, t->binPos, t->waveTile, t->tl, prod, t->lrow, y, TileDst{}, sig);
     if (hipEventRecord(evJoin, side) != hipSuccess || hipStreamWaitEvent(stream, evJoin, 0) != hipSuccess) return EXIT_FAILURE;
