@@ -130,6 +130,25 @@ def test_tiles_reduce_bin_ranges_single_process():
     scale = np.add.reduceat(np.abs(as_ * x_host[ja]), irp[:-1].astype(np.int64))
     assert not np.isnan(y).any()
     assert np.all(np.abs(y - y_ref) <= 1e-13 * scale + 1e-300)
+    # push kernel and fused store with an ODD first row (8-byte aligned vectors: the 16-byte copy peels one row) and
+    # several destinations; every destination must equal y bit for bit
+    big = [api.DeviceVector(w.N + 1) for _ in range(4)]
+    for mode in ("fused", "pushk"):
+        for v in big:
+            v.poison()
+        ptrs = [C.c_void_p(v.ptr.value + 8) for v in big]
+        extra = (C.c_void_p * 3)(*[p.value for p in ptrs[1:]])
+        assert api.lib.hipSpMVTilesExpand(C.byref(dm.handle), dx.ptr) == 0
+        if mode == "fused":
+            assert api.lib.hipSpMVTilesReduce(C.byref(dm.handle), 0, nb.value, ptrs[0], 3, extra) == 0
+        else:
+            assert api.lib.hipSpMVTilesReducePush(C.byref(dm.handle), ptrs[0], 3, extra) == 0
+            assert api.lib.spmvHipTilesPushFailed(C.byref(dm.handle)) == 0
+        got = [v.down()[1:] for v in big]
+        assert not np.isnan(got[0]).any() and np.all(np.abs(got[0] - y_ref) <= 1e-13 * scale + 1e-300)
+        for g in got[1:]:
+            assert np.array_equal(g, got[0]), mode
+    assert api.lib.hipSpMVTilesReducePush(C.byref(dm.handle), dy.ptr, 0, None) == 1        # needs a destination
     # invalid ranges fail loudly
     assert api.lib.hipSpMVTilesReduce(C.byref(dm.handle), 2, 1, dy.ptr, 0, None) == 1
     assert api.lib.hipSpMVTilesReduce(C.byref(dm.handle), 0, nb.value + 1, dy.ptr, 0, None) == 1
