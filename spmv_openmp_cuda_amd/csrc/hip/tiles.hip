@@ -17,9 +17,10 @@
 //            the bin's tile table (start, offset), so the products are read as runs
 //            of one tile each with all 64 lanes busy; ds_add_f64 into LDS, and the
 //            bin of y is stored at the end.
-// ~28-30 B/nnz of pure streaming instead of 12 B/nnz + one line per nnz.  Measured ceilings on
-// the box (scripts/microbench_copy.hip): a 10 B read : 8 B write stream runs at 5.0 TB/s, a pure
-// read stream at 6.5 TB/s -> phase 1 >= 5.8 ms and phase 2 >= ~3.4 ms for 1.6 G nnz.
+// ~28-30 B/nnz of pure streaming instead of 12 B/nnz + one line per nnz.  Measured on c5 (1.6 G nnz,
+// profiles/r01_summary.md): phase 1 5.4 ms = 5.8 TB/s of the bytes it moves, phase 2 3.4 ms = 6.0 TB/s.
+// Multi-GPU (one process per GPU): phase 2 can also deliver y to the other ranks -- stores fused into the
+// kernel, or a push kernel beside it fed by per-bin ready flags.
 //
 // Relation to the reference: its CPU variants spmvTilesCSR / spmvTilesAllocdCSR
 // (src/SpMV_CSR_OMP.c:101-226) use the same 2-D decomposition -- column
