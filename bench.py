@@ -428,15 +428,21 @@ def main():
     x = torch.from_numpy(x_host).cuda()
     cfg = api.CONFIG()
 
+    group_cache = {}
+
+    def group_setup(groups):
+        """(plan, this rank's device matrices) for `groups` row groups per rank; built once, freed at the end"""
+        if groups not in group_cache:
+            plan_g = sharding.make_plan(irp, world, groups)
+            group_cache[groups] = (plan_g, [synth.device_csr(w, irp, *plan_g.block(rank, g)) for g in range(groups)])
+        return group_cache[groups]
+
     class RcclExchange:
         """this rank's `groups` row groups as device matrices + gather buffers; kernel(g) -> async RCCL all-gather(g)"""
-        def __init__(self, groups, first=None):
+        def __init__(self, groups):
             self.groups = self.events = groups
             self.name = f"rccl-g{groups}"
-            self.plan = sharding.make_plan(irp, world, groups)
-            self.dms = [first] if (first is not None and groups == 1) else \
-                [synth.device_csr(w, irp, *self.plan.block(rank, g)) for g in range(groups)]
-            self.owns = not (first is not None and groups == 1)
+            self.plan, self.dms = group_setup(groups)
             self.bufs = sharding.GatherBuffers(self.plan, rank, torch, "cuda")
             self.y = self.bufs.y
             self.desc = (f"{world} ranks x {groups} nnz-balanced row groups; per group: kernel then async RCCL "
@@ -459,40 +465,42 @@ def main():
             return sharding.step(self.plan, dist, self.bufs, compute_group)
 
         def free(self):
-            if self.owns:
-                for dm in self.dms:
-                    dm.free()
             self.dms, self.bufs, self.y = [], None, None
 
     class PushExchange:
         """y lives in a peer window; this rank's rows are delivered to the other ranks' windows by copy-engine pushes
-        behind each piece of y ("push-pQ") or by stores fused into phase 2 of the two-phase kernel ("fused")"""
-        def __init__(self, px, dm, mode, pieces):
-            self.events = 1
-            self.plan = base_plan
-            self.run = sharding.PushSpMV(api, px, dm, base_plan.rows(rank)[0], launcher, x.data_ptr(), mode, pieces)
-            self.name = mode if mode in ("fused", "pushk") else f"push-p{self.run.pieces}"
+        behind each piece of y ("push-pQ"), by stores fused into phase 2 of the two-phase kernel ("fused") or by a push
+        kernel beside phase 2 ("pushk"); with G > 1 row groups per rank ("-gG") the rows of one group travel while the
+        next group is computed"""
+        def __init__(self, px, mode, pieces, groups=1):
+            self.groups = self.events = groups
+            self.plan, dms = group_setup(groups)
+            self.runs = [sharding.PushSpMV(api, px, dms[g], self.plan.block(rank, g)[0], launcher, x.data_ptr(), mode, pieces)
+                         for g in range(groups)]
+            self.px = px
+            self.name = (mode if mode in ("fused", "pushk") else f"push-p{self.runs[0].pieces}") + (f"-g{groups}" if groups > 1 else "")
             self.y = px.y
-            self.groups = 1
-            self.desc = (f"{world} ranks, one nnz-balanced row block each, y in peer windows (device IPC over xGMI): " +
+            self.desc = (f"{world} ranks x {groups} nnz-balanced row group(s), y in peer windows (device IPC over xGMI): " +
                          ("phase 2 stores every finished bin of y to all ranks itself" if mode == "fused" else
                           "a push kernel beside phase 2 copies every bin of y to all ranks as soon as it is flagged" if mode == "pushk" else
-                          f"{self.run.pieces} piece(s) of y, each pushed to all ranks by the copy engines while the next is reduced") +
+                          f"{self.runs[0].pieces} piece(s) of y, each pushed to all ranks by the copy engines while the next is reduced") +
                          "; step ends with a 4-byte RCCL all-reduce as barrier")
 
         def poison(self):
             self.y.fill_(float("nan"))
 
         def step(self, fn, ev=None):
-            return self.run.step(ev[0] if ev else None)
+            for g, run in enumerate(self.runs):
+                run.enqueue(ev[g] if ev else None)
+            self.px.finish()
+            return self.y
 
         def free(self):
-            self.run, self.y = None, None
+            self.runs, self.y = [], None
 
     # every rank must run the same kernel: rank 0 decides (on its block of the 1-group plan)
-    base_plan = sharding.make_plan(irp, world, 1)
-    base_dm = synth.device_csr(w, irp, *base_plan.block(rank, 0))
-    first = RcclExchange(1, base_dm)
+    base_plan, (base_dm,) = group_setup(1)
+    first = RcclExchange(1)
     launcher, tried = pick_launcher(api, torch, base_dm, x.data_ptr(), first.bufs.slot[0].data_ptr(), args.launcher)
     choice = torch.tensor([AUTO_CANDIDATES.index(launcher) if launcher in AUTO_CANDIDATES else -1], device="cuda")
     dist.broadcast(choice, 0)
@@ -516,13 +524,16 @@ def main():
                 yield (lambda G=G: first if G == 1 else RcclExchange(G))
         if px is not None and args.exchange in ("auto", "auto-no-rccl", "push"):
             for q in ([args.pieces] if args.pieces > 0 else ([1, 2, 4, 8] if launcher == "hipSpMVTilesCSR" else [1])):
-                yield (lambda q=q: PushExchange(px, base_dm, "push", q))
+                yield (lambda q=q: PushExchange(px, "push", q))
         # the fused store is tried only after a copy-engine push through the same mappings delivered a correct y
         if px is not None and args.exchange in ("auto", "auto-no-rccl", "fused") and launcher == "hipSpMVTilesCSR" and \
                 (args.exchange == "fused" or any(k.startswith("push") for k in exchange_ms)):
-            yield (lambda: PushExchange(px, base_dm, "fused", 1))
+            yield (lambda: PushExchange(px, "fused", 1))
             if world > 1:
-                yield (lambda: PushExchange(px, base_dm, "pushk", 1))
+                yield (lambda: PushExchange(px, "pushk", 1))
+                # two row groups per rank: the rows of the first travel under the kernels of the second
+                yield (lambda: PushExchange(px, "fused", 1, 2))
+                yield (lambda: PushExchange(px, "pushk", 1, 2))
     exchange_ms, rejected = {}, {}
     best, ref_sum = None, None
     for make in candidates():
@@ -530,6 +541,8 @@ def main():
         if cand.name in exchange_ms or cand.name in rejected:      # e.g. fewer pieces than asked for
             continue
         cand.poison()
+        torch.cuda.synchronize()
+        dist.barrier()                      # peers write into this rank's y: nobody steps before everybody has poisoned
         cand.step(fn)
         torch.cuda.synchronize()
         y_c = cand.y
@@ -601,6 +614,8 @@ def main():
         setup.step(fn, ev)
 
     setup.poison()
+    torch.cuda.synchronize()
+    dist.barrier()                          # as above: the warm-up steps of a fast rank must not land before a slow rank's poison
     wall = time_kernel_loop(api, torch, dist, world, step, steps, warmup, evs)
     kms = [sum(kernel_ms(api, per_step)) for per_step in evs]
     y = setup.y
@@ -642,7 +657,9 @@ def main():
     if setup is not first:
         setup.free()
     first.free()
-    base_dm.free()
+    for _, dms_g in group_cache.values():
+        for dm in dms_g:
+            dm.free()
     if px is not None:
         px.close()
     api.spmvHipFinalize()

@@ -220,9 +220,13 @@ int hipSpMVTilesReduce(spmat* dMat, unsigned binBegin, unsigned binEnd, double* 
 /* Phase 2 over all bins with a PUSH KERNEL beside it (own high-priority stream, no LDS, a few wavefronts per CU):
  * every reduction workgroup sets a per-bin flag when its rows of y are stored (agent-scope release), the push
  * kernel copies each flagged bin to the nExtra destinations.  The reduction never waits for a link and the links
- * work from the first finished bin on.  The library stream continues after both kernels.  A flag that does not
- * arrive within ~2 s makes the push kernel give up (spmvHipTilesPushFailed() == 1, y incomplete) rather than hang. */
+ * work from the first finished bin on.  With spmvHipSetSync(0) the library stream does NOT wait for the push
+ * kernel (the next row group's phase 1 may run while these rows still travel): spmvHipTilesPushJoin() makes it
+ * wait for every push kernel enqueued so far; in synchronous mode the call returns with everything delivered.
+ * A flag that does not arrive within ~2 s makes the push kernel give up (spmvHipTilesPushFailed() == 1, y
+ * incomplete) rather than hang. */
 int hipSpMVTilesReducePush(spmat* dMat, double* dY, int nExtra, double* const* dExtra);
+int spmvHipTilesPushJoin(void);
 int spmvHipTilesPushFailed(spmat* dMat);
 
 /* ------------------------------------------------- synthetic matrices on device */

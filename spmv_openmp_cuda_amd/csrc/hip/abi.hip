@@ -676,24 +676,35 @@ int hipSpMVTilesReduce(spmat* dMat, unsigned binBegin, unsigned binEnd, double* 
     return L.finish("hipSpMVTilesReduce");
 }
 
+namespace { hipStream_t g_pushSide = nullptr; hipEvent_t g_pushFork = nullptr, g_pushJoin = nullptr; bool g_pushPending = false; }
+
 int hipSpMVTilesReducePush(spmat* dMat, double* dY, int nExtra, double* const* dExtra) {
     DevMat* d = tilesReady(dMat, "hipSpMVTilesReducePush");
     if (!d) return EXIT_FAILURE;
     if (nExtra < 1 || nExtra > SPMV_MAX_PEERS || !dExtra || !dY) { ERR("hipSpMVTilesReducePush: %d destinations: invalid", nExtra); return EXIT_FAILURE; }
-    static hipStream_t side = nullptr;
-    static hipEvent_t evFork = nullptr, evJoin = nullptr;
-    if (!side) {
+    if (!g_pushSide) {
         int lo = 0, hi = 0;
         HIP_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));
-        HIP_TRY(hipStreamCreateWithPriority(&side, hipStreamNonBlocking, hi));      // dispatched ahead of phase 2's later rounds
-        HIP_TRY(hipEventCreateWithFlags(&evFork, hipEventDisableTiming));
-        HIP_TRY(hipEventCreateWithFlags(&evJoin, hipEventDisableTiming));
+        HIP_TRY(hipStreamCreateWithPriority(&g_pushSide, hipStreamNonBlocking, hi));      // dispatched ahead of phase 2's later rounds
+        HIP_TRY(hipEventCreateWithFlags(&g_pushFork, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&g_pushJoin, hipEventDisableTiming));
     }
     uint32_t b = 0, r = 0;
     tilesShape(d, &b, &r);
+    const bool wasSync = S.sync;
     Launch L(dim3(b), dim3(1024));
-    if (enqueueTilesReducePush(d, dY, nExtra, dExtra, S.stream, side, evFork, evJoin)) { ERR("hipSpMVTilesReducePush: launch failed"); return EXIT_FAILURE; }
+    if (enqueueTilesReducePush(d, dY, nExtra, dExtra, S.stream, g_pushSide, g_pushFork, g_pushJoin)) { ERR("hipSpMVTilesReducePush: launch failed"); return EXIT_FAILURE; }
+    g_pushPending = true;
+    if (wasSync && spmvHipTilesPushJoin()) return EXIT_FAILURE;         // synchronous mode: everything delivered on return
     return L.finish("hipSpMVTilesReducePush");
+}
+
+int spmvHipTilesPushJoin(void) {
+    if (g_pushPending) {
+        HIP_TRY(hipStreamWaitEvent(S.stream, g_pushJoin, 0));        // push kernels run in order on one stream: the last event covers all
+        g_pushPending = false;
+    }
+    return EXIT_SUCCESS;
 }
 
 int spmvHipTilesPushFailed(spmat* dMat) {

@@ -791,7 +791,8 @@ int enqueueTilesReduce(DevMat* d, uint32_t binBegin, uint32_t binEnd, double* y,
 }
 
 // phase 2 over all bins on `stream` with the push kernel beside it on `side`: `side` first waits for what is enqueued on
-// `stream` so far (phase 1), `stream` finally waits for the push kernel.  y and the nExtra destinations as above.
+// `stream` so far (phase 1); evJoin marks the end of the push kernel and `stream` does NOT wait for it here, so the
+// next row group's phase 1 can run while this group's rows are still travelling.  y and the destinations as above.
 int enqueueTilesReducePush(DevMat* d, double* y, int nExtra, double* const* extra, hipStream_t stream, hipStream_t side,
                            hipEvent_t evFork, hipEvent_t evJoin) {
     TileFormat* t = d->tiles;
@@ -813,7 +814,7 @@ int enqueueTilesReducePush(DevMat* d, double* y, int nExtra, double* const* extr
                        epoch, y, dst, t->pushFail);
     hipLaunchKernelGGL(pb_reduce_kernel<2>, grid2d((uint64_t)((t->B + 7) / 8) * 8, PB_THREADS), dim3(PB_THREADS), (size_t)8 * t->R, stream,
                        t->R, 0u, t->B, d->M, t->binPos, t->waveTile, t->tl, prod, t->lrow, y, TileDst{}, sig);
-    if (hipEventRecord(evJoin, side) != hipSuccess || hipStreamWaitEvent(stream, evJoin, 0) != hipSuccess) return EXIT_FAILURE;
+    if (hipEventRecord(evJoin, side) != hipSuccess) return EXIT_FAILURE;          // the caller joins (tilesPushJoin) when it needs y delivered
     return hipGetLastError() == hipSuccess ? EXIT_SUCCESS : EXIT_FAILURE;
 }
 

@@ -197,8 +197,8 @@ class PeerExchange:
 
     def finish(self, barrier=None):
         """own pushes done (in stream order), then a node-wide barrier: afterwards every rank's y is complete"""
-        if self.api.lib.spmvHipPeerPushJoin():
-            raise RuntimeError("spmvHipPeerPushJoin failed")
+        if self.api.lib.spmvHipPeerPushJoin() or self.api.lib.spmvHipTilesPushJoin():
+            raise RuntimeError("spmvHipPeerPushJoin / spmvHipTilesPushJoin failed")
         if barrier is not None:
             barrier()
         else:
@@ -258,6 +258,12 @@ class PushSpMV:
         self.pieces = len(self.ranges) if self.tiles else 1
 
     def step(self, ev=None):
+        self.enqueue(ev)
+        self.px.finish(self.barrier)
+        return self.px.y
+
+    def enqueue(self, ev=None):
+        """kernels and pushes of this block of rows, without the final join + barrier (PeerExchange.finish)"""
         import ctypes as C
         api, lib, h = self.api, self.api.lib, C.byref(self.dm.handle)
         if ev:
@@ -280,5 +286,3 @@ class PushSpMV:
             lib.spmvHipEventRecord(ev[1])
         if rc:
             raise RuntimeError(self.launcher + " failed")
-        self.px.finish(self.barrier)
-        return self.px.y
