@@ -139,10 +139,14 @@ int spmvHipEnqueueCSR(spmat* dMat, int warpPerRow, double* dX, double* dY, void*
  *                         2 = (default) same, second generation: scalar-loaded block
  *                             table, row pointers staged in LDS, long rows first,
  *                             XCD-contiguous block order
+ *                         3 = third generation: two row blocks per workgroup, the second
+ *                             block's loads in flight under the first one's reduction
+ *                             (measured 0-4 % slower than 2; kept for the A/B)
  *   hipSpMVWarpPerRowCSR  0 = one wavefront per row, __shfl_down tree
  *                         1 = adaptive: LDS segmented reduction for short rows,
  *                             wavefront-/workgroup-per-row for long ones
  *                         2 = (default) same, second generation
+ *                         3 = third generation (two row blocks per workgroup), as above
  * Returns EXIT_FAILURE for an unknown (launcher, variant). */
 int spmvHipSetVariant(const char* launcher, int variant);
 /* Use the RL array for ELL early exit (1, default when RL was uploaded) or walk

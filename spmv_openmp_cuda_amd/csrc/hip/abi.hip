@@ -231,6 +231,17 @@ static void launchStream2(DevMat* d, double* x, double* y) {
                            d->nBlk2, d->nLong2, d->blkInfo, d->blkBase, static_cast<const uint64_t*>(d->IRP), d->JA, d->AS, x, y);
 }
 
+template <bool SEQ>
+static void launchStream3(DevMat* d, double* x, double* y) {
+    const uint64_t wgs = (uint64_t)d->nLong2 + ((uint64_t)(d->nBlk2 - d->nLong2) + 1) / 2;
+    if (d->irpBytes == 4)
+        hipLaunchKernelGGL((csr_stream3_kernel<uint32_t, SEQ>), grid2d(wgs, WG_THREADS), dim3(WG_THREADS), 0, S.stream,
+                           d->nBlk2, d->nLong2, d->blkInfo, d->blkBase, static_cast<const uint32_t*>(d->IRP), d->JA, d->AS, x, y);
+    else
+        hipLaunchKernelGGL((csr_stream3_kernel<uint64_t, SEQ>), grid2d(wgs, WG_THREADS), dim3(WG_THREADS), 0, S.stream,
+                           d->nBlk2, d->nLong2, d->blkInfo, d->blkBase, static_cast<const uint64_t*>(d->IRP), d->JA, d->AS, x, y);
+}
+
 template <int G>
 static void launchEllGroup(DevMat* d, bool rl, dim3 grid, dim3 block, double* x, double* y) {
     if (rl) hipLaunchKernelGGL((ell_rowmajor_group<true, G>), grid, block, 0, S.stream, (uint32_t)d->M, (uint32_t)d->K, d->pitch, d->JA, d->AS, d->RL, x, y);
@@ -378,8 +389,8 @@ int spmvHipDeviceSynchronize(void) { HIP_TRY(hipDeviceSynchronize()); return EXI
 
 int spmvHipSetVariant(const char* launcher, int variant) {
     if (!launcher) return EXIT_FAILURE;
-    if (!strcmp(launcher, "hipSpMVRowsCSR") && variant >= 0 && variant <= 2) { S.variantRowsCSR = variant; return EXIT_SUCCESS; }
-    if (!strcmp(launcher, "hipSpMVWarpPerRowCSR") && variant >= 0 && variant <= 2) { S.variantWarpCSR = variant; return EXIT_SUCCESS; }
+    if (!strcmp(launcher, "hipSpMVRowsCSR") && variant >= 0 && variant <= 3) { S.variantRowsCSR = variant; return EXIT_SUCCESS; }
+    if (!strcmp(launcher, "hipSpMVWarpPerRowCSR") && variant >= 0 && variant <= 3) { S.variantWarpCSR = variant; return EXIT_SUCCESS; }
     ERR("spmvHipSetVariant: unknown (%s, %d)", launcher, variant);
     return EXIT_FAILURE;
 }
@@ -556,7 +567,7 @@ int hipSpMVRowsCSR(spmat* dMat, double* dX, CONFIG cfg, double* dY) {
         return L.finish("hipSpMVRowsCSR");
     }
     Launch L(grid2d(d->nBlk2, WG_THREADS), dim3(WG_THREADS));
-    launchStream2<true>(d, dX, dY);
+    if (S.variantRowsCSR == 3) launchStream3<true>(d, dX, dY); else launchStream2<true>(d, dX, dY);
     return L.finish("hipSpMVRowsCSR");
 }
 
@@ -581,7 +592,7 @@ int hipSpMVWarpPerRowCSR(spmat* dMat, double* dX, CONFIG cfg, double* dY) {
         return L.finish("hipSpMVWarpPerRowCSR");
     }
     Launch L(grid2d(d->nBlk2, WG_THREADS), dim3(WG_THREADS));
-    launchStream2<false>(d, dX, dY);
+    if (S.variantWarpCSR == 3) launchStream3<false>(d, dX, dY); else launchStream2<false>(d, dX, dY);
     return L.finish("hipSpMVWarpPerRowCSR");
 }
 

@@ -88,8 +88,9 @@ def _run(api, launcher, dmat, x, rows):
 
 @pytest.mark.parametrize("name", list(CASES))
 @pytest.mark.parametrize("launcher,variant,exact", [
-    ("hipSpMVRowsCSR", 0, True), ("hipSpMVRowsCSR", 1, True), ("hipSpMVRowsCSR", 2, True),
+    ("hipSpMVRowsCSR", 0, True), ("hipSpMVRowsCSR", 1, True), ("hipSpMVRowsCSR", 2, True), ("hipSpMVRowsCSR", 3, True),
     ("hipSpMVWarpPerRowCSR", 0, False), ("hipSpMVWarpPerRowCSR", 1, False), ("hipSpMVWarpPerRowCSR", 2, False),
+    ("hipSpMVWarpPerRowCSR", 3, False),
     ("hipSpMVTilesCSR", -1, False), ("hipSpMVRowsSELL", -1, False)])
 def test_csr(api, oracle, name, launcher, variant, exact):
     M, N, IRP, JA, AS = CASES[name]
@@ -269,7 +270,7 @@ def test_64bit_row_pointers_small(api, oracle):
     dm = api.DeviceMatrix()
     assert api.lib.spmvHipAdoptCSR(C.byref(dm.handle), M, N, JA.size, d_irp.ptr, 8, d_ja.ptr, d_as.ptr, None) == 0
     dm.keep = [d_irp, d_ja, d_as]
-    for launcher, variants, exact in (("hipSpMVRowsCSR", (0, 1, 2), True), ("hipSpMVWarpPerRowCSR", (0, 1, 2), False),
+    for launcher, variants, exact in (("hipSpMVRowsCSR", (0, 1, 2, 3), True), ("hipSpMVWarpPerRowCSR", (0, 1, 2, 3), False),
                                       ("hipSpMVTilesCSR", (-1,), False), ("hipSpMVRowsSELL", (-1,), False)):
         for v in variants:
             if v >= 0:
