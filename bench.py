@@ -5,9 +5,12 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 One "step" = one y = A.x over the whole matrix: every rank runs the hot kernel
-(hipSpMVWarpPerRowCSR through the C-ABI) on its nnz-balanced contiguous row
-block and, for N > 1, the ranks all-gather y over RCCL/xGMI so that each ends
-with the full vector (ready to be the next x).  The default workload is
+(a C-ABI launcher, picked among hipSpMVWarpPerRowCSR / hipSpMVTilesCSR / hipSpMVRowsSELL
+by timing them during warm-up) on its nnz-balanced contiguous row block and, for
+N > 1, the ranks exchange y over xGMI so that each ends with the full vector (ready
+to be the next x): an RCCL all-gather, copy-engine pushes into peer windows, stores
+fused into the producing kernel or a push kernel beside it -- whichever whole step
+measures fastest at start-up.  The default workload is
 BASELINE.json configs[4] (power-law CSR, 80 M rows / 1.6 G nnz, max row 50 k),
 the configuration the metric's 1/2/4/8-GPU curve is quoted on; it is kept
 whole at every N (strong scaling).  At N = 1 the same run also measures
