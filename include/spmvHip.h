@@ -219,6 +219,11 @@ int spmvHipPeerPushJoin(void);
  * all-gather fused into the kernel as direct xGMI stores).  Enqueue-only when
  * spmvHipSetSync(0).  spmvHipTilesShape builds the format if needed. */
 int spmvHipTilesShape(spmat* dMat, unsigned* nBins, unsigned* rowsPerBin);
+/* Rows per bin of the formats built AFTER this call (0 = automatic, else 64..20000).  Phase 2 finishes its bins in
+ * rounds of one workgroup per CU, and rows can only leave for the other ranks when their bin is finished: when the
+ * exchange is the longer part of a step, smaller bins (more rounds) let it start earlier, at the price of shorter
+ * tiles (N = 8 shard of c5: 1.19 ms automatic, 1.26 ms with half-size bins, 1.43 ms with quarter-size ones). */
+int spmvHipSetTilesRowsPerBin(unsigned rows);
 int hipSpMVTilesExpand(spmat* dMat, double* dX);
 int hipSpMVTilesReduce(spmat* dMat, unsigned binBegin, unsigned binEnd, double* dY, int nExtra, double* const* dExtra);
 /* Phase 2 over all bins with a PUSH KERNEL beside it (own high-priority stream, no LDS, a few wavefronts per CU):

@@ -79,7 +79,7 @@ _sigs = {
     "hipSpMVTilesExpand": ([C.POINTER(spmat), _vp], _i),
     "hipSpMVTilesReduce": ([C.POINTER(spmat), C.c_uint, C.c_uint, _vp, _i, _vp], _i),
     "hipSpMVTilesReducePush": ([C.POINTER(spmat), _vp, _i, _vp], _i), "spmvHipTilesPushFailed": ([C.POINTER(spmat)], _i),
-    "spmvHipTilesPushJoin": ([], _i),
+    "spmvHipTilesPushJoin": ([], _i), "spmvHipSetTilesRowsPerBin": ([C.c_uint], _i),
 }
 IPC_HANDLE_BYTES = 64
 MAX_PEERS = 15

@@ -665,6 +665,11 @@ int spmvHipTilesShape(spmat* dMat, unsigned* nBins, unsigned* rowsPerBin) {
     return EXIT_SUCCESS;
 }
 
+int spmvHipSetTilesRowsPerBin(unsigned rows) {
+    if (setTilesRowsPerBin(rows)) { ERR("spmvHipSetTilesRowsPerBin: %u is not 0 (automatic) or 64..20000", rows); return EXIT_FAILURE; }
+    return EXIT_SUCCESS;
+}
+
 int hipSpMVTilesExpand(spmat* dMat, double* dX) {
     DevMat* d = tilesReady(dMat, "hipSpMVTilesExpand");
     if (!d) return EXIT_FAILURE;

@@ -74,6 +74,7 @@ int  enqueueTilesReducePush(DevMat* d, double* y, int nExtra, double* const* ext
                             hipEvent_t evFork, hipEvent_t evJoin);
 int  tilesPushFailed(DevMat* d);
 void tilesShape(const DevMat* d, uint32_t* bins, uint32_t* rowsPerBin);
+int  setTilesRowsPerBin(uint32_t rows);
 hipStream_t libraryStream();                                    // abi.hip: the stream set with spmvHipSetStream
 size_t tilesBytes(const DevMat* d);
 

@@ -571,6 +571,13 @@ void freeTilesWorkspace() {
     (void)hipSetDevice(keep);
 }
 
+static uint32_t g_rowsPerBin = 0;                  // 0 = automatic
+int setTilesRowsPerBin(uint32_t rows) {
+    if (rows != 0 && (rows < 64 || rows > PB_R_MAX)) return EXIT_FAILURE;
+    g_rowsPerBin = rows;
+    return EXIT_SUCCESS;
+}
+
 void freeTiles(TileFormat* t) {
     if (!t) return;
     (void)hipFree(t->val); (void)hipFree(t->lcol); (void)hipFree(t->lrow); (void)hipFree(t->tl);
@@ -602,6 +609,7 @@ int buildTiles(DevMat* d) {
             R = std::min(R, PB_R_MAX);
         }
     }
+    if (g_rowsPerBin) R = g_rowsPerBin;                                                              // spmvHipSetTilesRowsPerBin
     if (const char* e = getenv("SPMV_PB_ROWS")) { const int v = atoi(e); if (v >= 64 && v <= (int)PB_R_MAX) R = (uint32_t)v; }   // tuning only
     t->R = R;
     t->B = (uint32_t)((M + R - 1) / R);
