@@ -44,10 +44,15 @@ template <int MODE> int run(const char* tag, const double* val, const uint16_t* 
 int main() {
     const size_t n = 1ull << 30;
     double *val, *out; uint16_t* col;
-    CK(hipMalloc(&val, n * 8)); CK(hipMalloc(&out, n * 8)); CK(hipMalloc(&col, n * 2));
+    CK(hipMalloc(&val, n * 8)); CK(hipMalloc(&out, n * 8 + (64 << 20))); CK(hipMalloc(&col, n * 2));
     CK(hipMemset(val, 0, n * 8)); CK(hipMemset(col, 0, n * 2));
     printf("store_flavour,ms,TBps (10 B read + 8 B written per entry, 1 Gi entries)\n");
     run<0>("plain", val, col, out, n); run<1>("nt", val, col, out, n); run<2>("sc1", val, col, out, n); run<3>("sc0 sc1", val, col, out, n);
     run<4>("sc0", val, col, out, n); run<5>("sc1 nt", val, col, out, n); run<6>("sc0 sc1 nt", val, col, out, n); run<7>("sc0 nt", val, col, out, n);
+    // does the relative placement of the written stream matter (channel / bank interleave)?  nt stores, out shifted
+    for (size_t off : {(size_t)0, (size_t)32, (size_t)512, (size_t)4096, (size_t)65536, (size_t)(1 << 20) + 4096, (size_t)(16 << 20) + 65536 + 512}) {
+        char tag[64]; snprintf(tag, sizeof tag, "nt out+%zu B", off * 8);
+        run<1>(tag, val, col, out + off, n - (32 << 20));
+    }
     return 0;
 }
