@@ -51,7 +51,7 @@ void printVector(double* v, ulong size);
 
 /* Inflate a .gz / .bz2 MatrixMarket file into `tmpFsDecompressPath` (in-process; the
  * reference shells out, utils.c:433-462).  0 = inflated, -1 = no compression suffix
- * (open `path` itself), 1 = failed / unsupported (.xz, .zip). */
+ * (open `path` itself), 1 = failed.  .gz, .bz2, .xz and .zip (first member) are inflated in-process. */
 int extractInTmpFS(char* path, char* tmpFsDecompressPath);
 
 #ifdef __cplusplus

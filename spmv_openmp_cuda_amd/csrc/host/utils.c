@@ -189,11 +189,99 @@ static int endsWith(const char* s, const char* suffix) {
     return a >= b && !strcmp(s + a - b, suffix);
 }
 
+/* whole file -> malloc'ed buffer (caller frees); NULL on error */
+static unsigned char* slurp(const char* path, size_t* len) {
+    FILE* f = fopen(path, "rb");
+    if (!f) { perror("fopen"); return NULL; }
+    unsigned char* b = NULL;
+    if (!fseek(f, 0, SEEK_END)) {
+        const long n = ftell(f);
+        if (n >= 0 && !fseek(f, 0, SEEK_SET) && (b = malloc((size_t)n + 1)) && fread(b, 1, (size_t)n, f) == (size_t)n) *len = (size_t)n;
+        else { free(b); b = NULL; }
+    }
+    fclose(f);
+    return b;
+}
+
+/* .xz: liblzma's single-call buffer decoder, loaded at run time (the image has the library but not its headers).
+ * The uncompressed size is not known up front: the output buffer is doubled until the decoder stops asking for more. */
+static int inflateXz(const char* path, FILE* out) {
+    void* so = dlopen("liblzma.so.5", RTLD_NOW);
+    if (!so) { ERRPRINTS("cannot load liblzma: %s\n", dlerror()); return 1; }
+    typedef int (*decode_fn)(uint64_t*, uint32_t, const void*, const uint8_t*, size_t*, size_t, uint8_t*, size_t*, size_t);
+    decode_fn decode = (decode_fn)dlsym(so, "lzma_stream_buffer_decode");
+    size_t inLen = 0;
+    unsigned char* in = decode ? slurp(path, &inLen) : NULL;
+    int rc = 1;
+    if (in) {
+        for (size_t cap = inLen * 8 + (1 << 16); cap <= ((size_t)1 << 36); cap *= 2) {
+            unsigned char* o = malloc(cap);
+            if (!o) break;
+            uint64_t memlimit = UINT64_MAX;
+            size_t inPos = 0, outPos = 0;
+            const int r = decode(&memlimit, 0, NULL, in, &inPos, inLen, o, &outPos, cap);     /* LZMA_OK = 0, LZMA_BUF_ERROR = 10 */
+            if (r == 0) rc = fwrite(o, 1, outPos, out) == outPos ? 0 : 1;
+            free(o);
+            if (r != 10) break;
+        }
+        free(in);
+    }
+    dlclose(so);
+    return rc;
+}
+
+/* .zip: the FIRST member of the archive (the reference unzips and reads the one file inside), method 0 (stored) or
+ * 8 (deflate, raw stream through zlib).  Sizes come from the central directory (members written by streaming zippers
+ * have zeros in their local header). */
+static uint32_t le32(const unsigned char* p) { return p[0] | p[1] << 8 | p[2] << 16 | (uint32_t)p[3] << 24; }
+static uint16_t le16(const unsigned char* p) { return (uint16_t)(p[0] | p[1] << 8); }
+static int inflateZip(const char* path, FILE* out) {
+    size_t n = 0;
+    unsigned char* z = slurp(path, &n);
+    if (!z) return 1;
+    int rc = 1;
+    size_t eocd = n;                                 /* end-of-central-directory record: PK\5\6, within the last 64 KiB */
+    for (size_t i = n >= 22 ? n - 22 : 0; n >= 22 && i + 65557 >= n; --i) {
+        if (le32(z + i) == 0x06054b50u) { eocd = i; break; }
+        if (i == 0) break;
+    }
+    if (eocd == n) { ERRPRINTS("%s: no zip end-of-central-directory record\n", path); goto done; }
+    {
+        const size_t cd = le32(z + eocd + 16);
+        if (cd + 46 > n || le32(z + cd) != 0x02014b50u) { ERRPRINTS("%s: bad zip central directory\n", path); goto done; }
+        const uint16_t method = le16(z + cd + 10);
+        const size_t csize = le32(z + cd + 20), usize = le32(z + cd + 24), lh = le32(z + cd + 42);
+        if (lh + 30 > n || le32(z + lh) != 0x04034b50u) { ERRPRINTS("%s: bad zip local header\n", path); goto done; }
+        const size_t data = lh + 30 + le16(z + lh + 26) + le16(z + lh + 28);
+        if (csize == 0xFFFFFFFFu || usize == 0xFFFFFFFFu || data + csize > n) { ERRPRINTS("%s: zip64 / truncated member not supported\n", path); goto done; }
+        if (method == 0) rc = fwrite(z + data, 1, csize, out) == csize ? 0 : 1;
+        else if (method == 8) {
+            unsigned char* o = malloc(usize ? usize : 1);
+            z_stream st;
+            memset(&st, 0, sizeof st);
+            if (o && inflateInit2(&st, -MAX_WBITS) == Z_OK) {
+                st.next_in = z + data; st.avail_in = (uInt)csize; st.next_out = o; st.avail_out = (uInt)usize;
+                const int r = inflate(&st, Z_FINISH);
+                if (r == Z_STREAM_END && st.total_out == usize) rc = fwrite(o, 1, usize, out) == usize ? 0 : 1;
+                inflateEnd(&st);
+            }
+            free(o);
+        } else ERRPRINTS("%s: zip compression method %u not supported\n", path, method);
+    }
+done:
+    free(z);
+    return rc;
+}
+
 int extractInTmpFS(char* path, char* tmpFsDecompressPath) {
     const int gz = endsWith(path, ".gz"), bz = endsWith(path, ".bz2");
     if (endsWith(path, ".xz") || endsWith(path, ".zip")) {
-        ERRPRINTS("NOT SUPPORTED DECOMPRESS FOR %s (only .gz and .bz2 are inflated in-process)\n", path);
-        return 1;
+        FILE* o = fopen(tmpFsDecompressPath, "wb");
+        if (!o) { perror("fopen decompress target"); return 1; }
+        int r = endsWith(path, ".xz") ? inflateXz(path, o) : inflateZip(path, o);
+        if (fclose(o)) r = 1;
+        if (r) ERRPRINTS("decompression of %s failed\n", path);
+        return r;
     }
     if (!gz && !bz) return -1;
     FILE* out = fopen(tmpFsDecompressPath, "wb");

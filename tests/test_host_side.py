@@ -189,22 +189,42 @@ def test_powerlaw_law_and_permutation():
 
 
 def test_compressed_inputs(tmp_path):
-    """.gz / .bz2 MatrixMarket files are inflated in-process (the reference shells out); .xz is refused."""
+    """.gz / .bz2 / .xz / .zip MatrixMarket files are inflated in-process (the reference shells out to gzip, xz, bzip2 and
+    unzip, utils.c:433-462): zlib, libbz2 and liblzma (both loaded at run time), and a zip reader over zlib's raw inflate
+    (first member; stored and deflated)."""
     import bz2
     import gzip
+    import io
+    import lzma
+    import zipfile
     H.extractInTmpFS.argtypes = [C.c_char_p, C.c_char_p]
     raw = open(os.path.join(GOLD, "cage4like.mtx"), "rb").read()
+    big = open(os.path.join(GOLD, "rand300.mtx"), "rb").read()        # larger than the first guess of the xz output buffer / 8
     g = load_golden("cage4like")
-    for name, data in (("m.mtx.gz", gzip.compress(raw)), ("m.mtx.bz2", bz2.compress(raw))):
+
+    def zipped(data, method):
+        b = io.BytesIO()
+        with zipfile.ZipFile(b, "w", method) as z:
+            z.writestr("inner.mtx", data)
+        return b.getvalue()
+    cases = [("m.mtx.gz", gzip.compress(raw), raw), ("m.mtx.bz2", bz2.compress(raw), raw), ("m.mtx.xz", lzma.compress(raw), raw),
+             ("b.mtx.xz", lzma.compress(big * 40), big * 40), ("m.mtx.zip", zipped(raw, zipfile.ZIP_DEFLATED), raw),
+             ("s.mtx.zip", zipped(raw, zipfile.ZIP_STORED), raw), ("b.mtx.zip", zipped(big, zipfile.ZIP_DEFLATED), big)]
+    for name, data, want in cases:
         src = tmp_path / name
         src.write_bytes(data)
         dst = str(tmp_path / "extracted").encode()
-        assert H.extractInTmpFS(str(src).encode(), dst) == 0
-        assert open(dst, "rb").read() == raw
-        m = H.MMtoCSR(dst).contents
-        assert m.NZ == g["NZ"] and np.array_equal(_arr(m.JA, m.NZ, np.uint64), g["JA"])
+        assert H.extractInTmpFS(str(src).encode(), dst) == 0, name
+        assert open(dst, "rb").read() == want, name
+        if want is raw:
+            m = H.MMtoCSR(dst).contents
+            assert m.NZ == g["NZ"] and np.array_equal(_arr(m.JA, m.NZ, np.uint64), g["JA"])
+    for name, data in (("bad.mtx.xz", b"not an xz stream"), ("bad.mtx.zip", b"PK not a zip"), ("trunc.mtx.zip", zipped(raw, zipfile.ZIP_DEFLATED)[:60])):
+        src = tmp_path / name
+        src.write_bytes(data)
+        assert H.extractInTmpFS(str(src).encode(), str(tmp_path / "x").encode()) == 1, name
     plain = tmp_path / "p.mtx"
     plain.write_bytes(raw)
     assert H.extractInTmpFS(str(plain).encode(), str(tmp_path / "x").encode()) == -1      # not compressed
-    assert H.extractInTmpFS(b"/tmp/whatever.mtx.xz", str(tmp_path / "x").encode()) == 1     # unsupported
+    assert H.extractInTmpFS(b"/nonexistent/whatever.mtx.xz", str(tmp_path / "x").encode()) == 1
     assert H.extractInTmpFS(b"/nonexistent/file.mtx.gz", str(tmp_path / "x").encode()) == 1
