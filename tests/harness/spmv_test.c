@@ -49,23 +49,35 @@ static void perfLine(const char* tag, double bytes, ulong nnz, double seconds) {
            2.0 * nnz / seconds * 1e-9, bytes / seconds * 1e-9, bytes / seconds / 8e12);
 }
 
+/* DECREASE_THREAD_NUM (a compile-time macro in the reference, test/SpMV_test.cu:73-78,97-99; an environment variable
+ * here): repeat the measurement with omp_get_max_threads(), ..., 2, 1 threads, one "threadNum:" line each. */
 static int testSpMVImplOMP(SPMV_INTERF f, spmat* mat, double* vector, double* outV, double* oracleOut) {
     double times[AVG_TIMES_ITERATION], timesInternal[AVG_TIMES_ITERATION], st[2], sti[2];
-    for (uint i = 0; i < AVG_TIMES_ITERATION; i++) {
-        for (ulong r = 0; r < mat->M; ++r) outV[r] = NAN;
-        double start = omp_get_wtime();
-        if (f(mat, vector, &Conf, outV)) { ERRPRINTS("compute func at:%p failed...\n", (void*)f); return EXIT_FAILURE; }
-        double end = omp_get_wtime();
-        if (doubleVectorsDiff(oracleOut, outV, mat->M, NULL)) return EXIT_FAILURE;
-        times[i] = end - start;
-        timesInternal[i] = ElapsedInternal;
-        ElapsedInternal = Elapsed = 0;
+    const char* sweep = getenv("DECREASE_THREAD_NUM");
+    const int tMax = (int)Conf.threadNum, tMin = (sweep && *sweep && *sweep != '0') ? 1 : tMax;
+    int rc = EXIT_SUCCESS;
+    for (int t = tMax; t >= tMin && rc == EXIT_SUCCESS; t--) {
+        omp_set_num_threads(t);
+        Conf.threadNum = (uint)t;
+        for (uint i = 0; i < AVG_TIMES_ITERATION; i++) {
+            for (ulong r = 0; r < mat->M; ++r) outV[r] = NAN;
+            double start = omp_get_wtime();
+            if (f(mat, vector, &Conf, outV)) { ERRPRINTS("compute func at:%p failed...\n", (void*)f); rc = EXIT_FAILURE; break; }
+            double end = omp_get_wtime();
+            if (doubleVectorsDiff(oracleOut, outV, mat->M, NULL)) { rc = EXIT_FAILURE; break; }
+            times[i] = end - start;
+            timesInternal[i] = ElapsedInternal;
+            ElapsedInternal = Elapsed = 0;
+        }
+        if (rc) break;
+        statsAvgVar(times, AVG_TIMES_ITERATION, st);
+        statsAvgVar(timesInternal, AVG_TIMES_ITERATION, sti);
+        printf("threadNum: %d\tompGridSize: %ux%u\ttimeAvg:%le timeVar:%le\ttimeInternalAvg:%le timeInternalVar:%le \n",
+               t, Conf.gridRows, Conf.gridCols, st[0], st[1], sti[0], sti[1]);
     }
-    statsAvgVar(times, AVG_TIMES_ITERATION, st);
-    statsAvgVar(timesInternal, AVG_TIMES_ITERATION, sti);
-    printf("threadNum: %d\tompGridSize: %ux%u\ttimeAvg:%le timeVar:%le\ttimeInternalAvg:%le timeInternalVar:%le \n",
-           (int)Conf.threadNum, Conf.gridRows, Conf.gridCols, st[0], st[1], sti[0], sti[1]);
-    return EXIT_SUCCESS;
+    omp_set_num_threads(tMax);
+    Conf.threadNum = (uint)tMax;
+    return rc;
 }
 
 static int testSpMVImplHip(SPMV_HIP_INTERF f, spmat* dMat, ulong rows, double* dVect, double* dOutV,

@@ -75,6 +75,16 @@ def test_harness_all_implementations_pass(name):
     assert "AVG_TIMES_ITERATION:25" in out and "MAX_ROW_NZ" in out and "omp sched gather:" in out
 
 
+def test_harness_thread_sweep():
+    """DECREASE_THREAD_NUM (test/SpMV_test.cu:73-78): every OpenMP implementation measured with 3, 2 and 1 threads"""
+    r = subprocess.run([HARNESS, os.path.join(GOLD, "rand300.mtx"), os.path.join(GOLD, "x_rand300.bin")],
+                       capture_output=True, text=True, timeout=300, env=dict(os.environ, OMP_NUM_THREADS="3", DECREASE_THREAD_NUM="1"))
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert r.stdout.count("threadNum:") == 8 * 3
+    for t in (3, 2, 1):
+        assert r.stdout.count(f"threadNum: {t}\t") == 8
+
+
 def test_sharded_single_process_path(oracle):
     from spmv_openmp_cuda_amd import api
     api.spmvHipInit(0)
