@@ -271,6 +271,26 @@ def cpu_baseline_and_check(api, synth, w, irp, x_host, y_gpu_fn, sample_nnz, ite
         dyn = timed_passes()
         extra_sched = {"omp_dynamic_fair_folded_gflops": 2.0 * nnz_s / (sum(dyn) / len(dyn)) * 1e-9}
         ref.refSetSchedule(1, 0)
+        cfg.chunkDistrbFunc = ref.refChunksNOOP()
+        # third figure of SURVEY 8d: the reference compiled with SIMD_ROWS_REDUCTION off, static schedule
+        nosimd_path = os.path.join(ROOT, "oracle", "_ref", "libspmvref_nosimd.so")
+        if os.path.exists(nosimd_path):
+            ref2 = C.CDLL(nosimd_path)
+            ref2.refChunksNOOP.restype = vp
+            ref2.refSetSchedule(1, 0)
+            cfg2 = ref_CONFIG()
+            cfg2.gridRows = cfg2.gridCols = 8
+            cfg2.threadNum = ref2.refMaxThreads()
+            cfg2.chunkDistrbFunc = ref2.refChunksNOOP()
+            ref2.spmvRowsBasicCSR.argtypes = [C.POINTER(ref_spmat), vp, C.POINTER(ref_CONFIG), vp]
+            y2 = np.empty(rows)
+            ts2 = []
+            for _ in range(iters + 1):
+                t0 = time.perf_counter()
+                rc = ref2.spmvRowsBasicCSR(C.byref(m), x_host.ctypes.data_as(vp), C.byref(cfg2), y2.ctypes.data_as(vp))
+                ts2.append(time.perf_counter() - t0)
+                assert rc == 0
+            extra_sched["omp_static_no_simd_reduction_gflops"] = 2.0 * nnz_s / (sum(ts2[1:]) / len(ts2[1:])) * 1e-9
     else:
         kind = "port"
         ora.oracleSetSchedule(1, 0)
