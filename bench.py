@@ -578,8 +578,19 @@ def main():
                 yield (lambda: PushExchange(px, "fused", 1, 2, 2))
     exchange_ms, rejected = {}, {}
     best, ref_sum = None, None
-    for make in candidates():
-        cand = make()
+    for k_cand, make in enumerate(candidates()):
+        try:                                    # a candidate that cannot be set up on SOME rank is dropped on ALL of them
+            cand = make()
+        except Exception as e:                  # noqa: BLE001 -- e.g. out of memory for one more copy of the format
+            cand = None
+            log(f"exchange candidate #{k_cand} could not be set up on rank {rank}: {e}")
+        built = torch.tensor([1.0 if cand is not None else 0.0], dtype=torch.float64, device="cuda")
+        dist.all_reduce(built, op=dist.ReduceOp.MIN)
+        if float(built[0]) == 0.0:
+            rejected[f"candidate#{k_cand}"] = "set-up failed on some rank"
+            if cand is not None and cand is not first:
+                cand.free()
+            continue
         if cand.name in exchange_ms or cand.name in rejected:      # e.g. fewer pieces than asked for
             continue
         cand.poison()
