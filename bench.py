@@ -453,23 +453,27 @@ def main():
 
     group_cache = {}
 
-    def group_setup(groups, rdiv=1):
+    def group_setup(groups, rdiv=1, taper=False):
         """(plan, this rank's device matrices) for `groups` row groups per rank; built once, freed at the end.
-        rdiv > 1: separate copies whose two-phase format has bins of 1/rdiv the automatic height (more rounds of bins
-        in phase 2, so the exchange of y can start earlier)"""
-        key = (groups, rdiv)
+        rdiv > 1 / taper: separate copies whose two-phase format has bins of 1/rdiv the automatic height, or tapered
+        bins (one round of quarter-height bins first and last) -- more, lower rounds of bins in phase 2, so that the
+        exchange of y can start earlier and has less left to send when the kernel ends"""
+        key = (groups, rdiv, taper)
         if key not in group_cache:
             plan_g = sharding.make_plan(irp, world, groups)
             dms = [synth.device_csr(w, irp, *plan_g.block(rank, g)) for g in range(groups)]
-            if rdiv > 1:
+            if rdiv > 1 or taper:
                 _, auto_dms = group_setup(groups)
                 for dm, ref in zip(dms, auto_dms):
                     nb, rpb = C.c_uint(), C.c_uint()
                     ok = dm.nnz > 0 and api.lib.spmvHipTilesShape(C.byref(ref.handle), C.byref(nb), C.byref(rpb)) == 0
                     if ok:
-                        api.lib.spmvHipSetTilesRowsPerBin(max(64, (rpb.value // rdiv + 63) // 64 * 64))
+                        if rdiv > 1:
+                            api.lib.spmvHipSetTilesRowsPerBin(max(64, (rpb.value // rdiv + 63) // 64 * 64))
+                        api.lib.spmvHipSetTilesTaper(1 if taper else 0)
                         api.lib.spmvHipBuildTiles(C.byref(dm.handle))
                         api.lib.spmvHipSetTilesRowsPerBin(0)
+                        api.lib.spmvHipSetTilesTaper(0)
             group_cache[key] = (plan_g, dms)
         return group_cache[key]
 
@@ -508,20 +512,21 @@ def main():
         behind each piece of y ("push-pQ"), by stores fused into phase 2 of the two-phase kernel ("fused") or by a push
         kernel beside phase 2 ("pushk"); with G > 1 row groups per rank ("-gG") the rows of one group travel while the
         next group is computed"""
-        def __init__(self, px, mode, pieces, groups=1, rdiv=1):
+        def __init__(self, px, mode, pieces, groups=1, rdiv=1, taper=False):
             self.groups = self.events = groups
-            self.plan, dms = group_setup(groups, rdiv)
+            self.plan, dms = group_setup(groups, rdiv, taper)
             self.runs = [sharding.PushSpMV(api, px, dms[g], self.plan.block(rank, g)[0], launcher, x.data_ptr(), mode, pieces)
                          for g in range(groups)]
             self.px = px
             self.name = (mode if mode in ("fused", "pushk") else f"push-p{self.runs[0].pieces}") + (f"-g{groups}" if groups > 1 else "") + \
-                (f"-r{rdiv}" if rdiv > 1 else "")
+                (f"-r{rdiv}" if rdiv > 1 else "") + ("-t" if taper else "")
             self.y = px.y
             self.desc = (f"{world} ranks x {groups} nnz-balanced row group(s), y in peer windows (device IPC over xGMI): " +
                          ("phase 2 stores every finished bin of y to all ranks itself" if mode == "fused" else
                           "a push kernel beside phase 2 copies every bin of y to all ranks as soon as it is flagged" if mode == "pushk" else
                           f"{self.runs[0].pieces} piece(s) of y, each pushed to all ranks by the copy engines while the next is reduced") +
                          (f"; bins of 1/{rdiv} the automatic height" if rdiv > 1 else "") +
+                         ("; tapered bins (a round of quarter-height bins first and last)" if taper else "") +
                          "; step ends with a 4-byte RCCL all-reduce as barrier")
 
         def poison(self):
@@ -576,6 +581,8 @@ def main():
                 yield (lambda: PushExchange(px, "fused", 1, 1, 2))
                 yield (lambda: PushExchange(px, "fused", 1, 1, 4))
                 yield (lambda: PushExchange(px, "fused", 1, 2, 2))
+                yield (lambda: PushExchange(px, "fused", 1, 1, 1, True))
+                yield (lambda: PushExchange(px, "fused", 1, 2, 1, True))
     exchange_ms, rejected = {}, {}
     best, ref_sum = None, None
     for k_cand, make in enumerate(candidates()):

@@ -224,6 +224,12 @@ int spmvHipTilesShape(spmat* dMat, unsigned* nBins, unsigned* rowsPerBin);
  * exchange is the longer part of a step, smaller bins (more rounds) let it start earlier, at the price of shorter
  * tiles (N = 8 shard of c5: 1.19 ms automatic, 1.26 ms with half-size bins, 1.43 ms with quarter-size ones). */
 int spmvHipSetTilesRowsPerBin(unsigned rows);
+/* Tapered bins for the formats built AFTER this call: one round (256) of quarter-height bins first and last, full-
+ * height bins between -- the first round sets when rows start to travel, the last what is still to be sent when
+ * phase 2 ends, the bins between keep the tile length.  rowsPerBin of spmvHipTilesShape is then the height of
+ * the HIGHEST bin; spmvHipTilesBinRow gives the first row of any bin (bin == nBins: the row count). */
+int spmvHipSetTilesTaper(int on);
+int spmvHipTilesBinRow(spmat* dMat, unsigned bin, ulong* firstRow);
 int hipSpMVTilesExpand(spmat* dMat, double* dX);
 int hipSpMVTilesReduce(spmat* dMat, unsigned binBegin, unsigned binEnd, double* dY, int nExtra, double* const* dExtra);
 /* Phase 2 over all bins with a PUSH KERNEL beside it (own high-priority stream, no LDS, a few wavefronts per CU):

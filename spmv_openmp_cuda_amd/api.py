@@ -80,6 +80,7 @@ _sigs = {
     "hipSpMVTilesReduce": ([C.POINTER(spmat), C.c_uint, C.c_uint, _vp, _i, _vp], _i),
     "hipSpMVTilesReducePush": ([C.POINTER(spmat), _vp, _i, _vp], _i), "spmvHipTilesPushFailed": ([C.POINTER(spmat)], _i),
     "spmvHipTilesPushJoin": ([], _i), "spmvHipSetTilesRowsPerBin": ([C.c_uint], _i),
+    "spmvHipSetTilesTaper": ([_i], _i), "spmvHipTilesBinRow": ([C.POINTER(spmat), C.c_uint, C.POINTER(C.c_ulong)], _i),
 }
 IPC_HANDLE_BYTES = 64
 MAX_PEERS = 15

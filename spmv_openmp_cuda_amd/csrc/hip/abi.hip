@@ -670,6 +670,15 @@ int spmvHipSetTilesRowsPerBin(unsigned rows) {
     return EXIT_SUCCESS;
 }
 
+int spmvHipSetTilesTaper(int on) { return setTilesTaper(on); }
+
+int spmvHipTilesBinRow(spmat* dMat, unsigned bin, ulong* firstRow) {
+    DevMat* d = tilesReady(dMat, "spmvHipTilesBinRow");
+    if (!d || !firstRow) return EXIT_FAILURE;
+    *firstRow = tilesBinRow(d, bin);
+    return EXIT_SUCCESS;
+}
+
 int hipSpMVTilesExpand(spmat* dMat, double* dX) {
     DevMat* d = tilesReady(dMat, "hipSpMVTilesExpand");
     if (!d) return EXIT_FAILURE;

@@ -75,6 +75,8 @@ int  enqueueTilesReducePush(DevMat* d, double* y, int nExtra, double* const* ext
 int  tilesPushFailed(DevMat* d);
 void tilesShape(const DevMat* d, uint32_t* bins, uint32_t* rowsPerBin);
 int  setTilesRowsPerBin(uint32_t rows);
+int  setTilesTaper(int on);
+uint64_t tilesBinRow(const DevMat* d, uint32_t bin);
 hipStream_t libraryStream();                                    // abi.hip: the stream set with spmvHipSetStream
 size_t tilesBytes(const DevMat* d);
 

@@ -58,8 +58,28 @@ constexpr uint32_t PB_CHUNK   = 1u << 17;           // entries of one slice hand
 constexpr int      PB_THREADS = 1024;
 constexpr size_t   PB_RESIDENT_BYTES = 288ull << 20; // products up to this size stay in the 256 MiB Infinity Cache between the phases (c2, 244 MiB: 0.156 ms plain vs 0.176 ms nt stores)
 
+// Rows -> bins.  Up to three zones of equal-height bins: n1 bins of a rows, n2 bins of b rows, the rest c rows
+// each.  Uniform formats use the last zone only (n1 = n2 = 0, c = R).  The TAPERED form -- one round of low bins
+// first and last, full-height bins between -- exists for the multi-GPU exchange: phase 2 finishes its bins in
+// rounds and a row can only leave for the other ranks once its bin is finished, so the height of the FIRST round
+// sets when the links start to work and the height of the LAST round what is still to be sent when the kernel
+// ends, while the tile length (= efficiency) is set by the bins between.
+struct BinMap {
+    uint32_t n1 = 0, n2 = 0, a = 1, b = 1, c = 1;
+    uint64_t z1 = 0, z2 = 0;                        // first row of zone 2 / zone 3
+    __host__ __device__ uint32_t binOf(uint64_t row) const {
+        return row < z1 ? (uint32_t)(row / a) : row < z2 ? n1 + (uint32_t)((row - z1) / b) : n1 + n2 + (uint32_t)((row - z2) / c);
+    }
+    __host__ __device__ uint64_t row0(uint32_t bin) const {
+        return bin < n1 ? (uint64_t)bin * a : bin < n1 + n2 ? z1 + (uint64_t)(bin - n1) * b : z2 + (uint64_t)(bin - n1 - n2) * c;
+    }
+    __host__ __device__ uint32_t height(uint32_t bin) const { return bin < n1 ? a : bin < n1 + n2 ? b : c; }
+    __host__ __device__ uint32_t maxHeight() const { uint32_t m = c; if (n1 && a > m) m = a; if (n2 && b > m) m = b; return m; }
+};
+
 struct TileFormat {
-    uint32_t S = 0, B = 0, R = 0;                   // slices, bins, rows per bin
+    uint32_t S = 0, B = 0, R = 0;                   // slices, bins, rows of the highest bin
+    BinMap    bins;
     uint64_t nnz = 0;
     double*   val = nullptr;                        // slice-major values
     uint16_t* lcol = nullptr;                       // slice-major: column - slice*PB_C
@@ -106,13 +126,13 @@ __global__ __launch_bounds__(256) void pb_keys_kernel(uint64_t nnz, const uint32
 // along that order, so the first entry of a tile also fills the start of every empty tile before it.
 __global__ __launch_bounds__(256) void pb_bounds_kernel(
     uint64_t nnz, const uint32_t* __restrict__ perm, const uint16_t* __restrict__ skeys, const uint32_t* __restrict__ rowOf,
-    uint32_t B, uint32_t R, uint64_t nTiles, uint32_t* __restrict__ tileStart) {
+    uint32_t B, BinMap bm, uint64_t nTiles, uint32_t* __restrict__ tileStart) {
     const uint64_t p = lin_block() * 256 + threadIdx.x;
     if (p >= nnz) return;
-    const uint64_t t = (uint64_t)skeys[p] * B + (rowOf[perm[p]] / R);
+    const uint64_t t = (uint64_t)skeys[p] * B + bm.binOf(rowOf[perm[p]]);
     uint64_t tPrev;                                  // tile of the previous entry, or "-1"
     if (p == 0) tPrev = ~0ull;
-    else tPrev = (uint64_t)skeys[p - 1] * B + (rowOf[perm[p - 1]] / R);
+    else tPrev = (uint64_t)skeys[p - 1] * B + bm.binOf(rowOf[perm[p - 1]]);
     if (t != tPrev)
         for (uint64_t u = tPrev + 1; u <= t; ++u) tileStart[u] = (uint32_t)p;      // tPrev+1 wraps to 0 for p == 0
     if (p == nnz - 1)
@@ -152,16 +172,16 @@ __global__ __launch_bounds__(256) void pb_list_kernel(uint32_t S, uint32_t B, ui
 __global__ __launch_bounds__(256) void pb_gather_kernel(
     uint64_t nnz, const uint32_t* __restrict__ perm, const uint16_t* __restrict__ skeys,
     const uint32_t* __restrict__ rowOf, const uint32_t* __restrict__ JA, const double* __restrict__ AS,
-    uint32_t S, uint32_t B, uint32_t R, const uint32_t* __restrict__ tileStart, const uint32_t* __restrict__ bmStart,
+    uint32_t S, uint32_t B, BinMap bm, const uint32_t* __restrict__ tileStart, const uint32_t* __restrict__ bmStart,
     double* __restrict__ val, uint16_t* __restrict__ lcol, uint16_t* __restrict__ lrow) {
     const uint64_t p = lin_block() * 256 + threadIdx.x;
     if (p >= nnz) return;
     const uint32_t j = perm[p];
-    const uint32_t row = rowOf[j], bin = row / R, slice = skeys[p];
+    const uint32_t row = rowOf[j], bin = bm.binOf(row), slice = skeys[p];
     val[p] = AS[j];
     lcol[p] = (uint16_t)(JA[j] % PB_C);
     const uint32_t within = (uint32_t)p - tileStart[(uint64_t)slice * B + bin];
-    lrow[bmStart[(uint64_t)bin * S + slice] + within] = (uint16_t)(row - bin * R);
+    lrow[bmStart[(uint64_t)bin * S + slice] + within] = (uint16_t)(row - bm.row0(bin));
 }
 
 __global__ __launch_bounds__(256) void pb_fill_kernel(uint32_t* p, uint64_t n, uint32_t v) {
@@ -346,7 +366,7 @@ __device__ __forceinline__ void p2_add_runs(double* yb, uint16_t rv, double pv, 
 // is fused into the producing kernel as point-to-point stores, one 512-B run per wavefront instruction.
 template <int MODE>                                 // 0: y only; 1: y + extra destinations; 2: y + per-bin ready flag
 __global__ __launch_bounds__(PB_THREADS) void pb_reduce_kernel(
-    uint32_t R, uint32_t binBegin, uint32_t binEnd, uint64_t M, const uint32_t* __restrict__ binPos, const uint32_t* __restrict__ waveTile,
+    BinMap bm, uint32_t binBegin, uint32_t binEnd, uint64_t M, const uint32_t* __restrict__ binPos, const uint32_t* __restrict__ waveTile,
     const uint2* __restrict__ tl, const double* __restrict__ prod, const uint16_t* __restrict__ lrow,
     double* __restrict__ y, TileDst extra, TileSignal sig) {
     extern __shared__ double yb[];                  // R doubles
@@ -377,6 +397,7 @@ __global__ __launch_bounds__(PB_THREADS) void pb_reduce_kernel(
         c.n2 = tl[c.k + 2];
         p2_fetch(a, c, wb, we, lane, tl, prod, lrow);                   // moving before the bin is zeroed
     }
+    const uint32_t R = bm.height((uint32_t)bin);
     for (uint32_t k = threadIdx.x; k < R; k += PB_THREADS) yb[k] = 0.0;
     __syncthreads();
     if (busy) {
@@ -405,7 +426,7 @@ __global__ __launch_bounds__(PB_THREADS) void pb_reduce_kernel(
         }
     }
     __syncthreads();
-    const uint64_t r0 = bin * R;
+    const uint64_t r0 = bm.row0((uint32_t)bin);
     for (uint32_t k = threadIdx.x; k < R; k += PB_THREADS)
         if (r0 + k < M) y[r0 + k] = yb[k];
     if (MODE == 1) {
@@ -450,7 +471,7 @@ constexpr int      PUSH_DEPTH = 8;
 constexpr uint32_t PUSH_WGS = SPMV_PUSH_WGS;
 constexpr uint32_t PUSH_SPIN_LIMIT = 1u << 20;
 __global__ __launch_bounds__(PUSH_THREADS) void pb_push_kernel(
-    uint32_t R, uint32_t B, uint64_t M, const uint32_t* __restrict__ ready, uint32_t epoch, const double* __restrict__ y,
+    BinMap bm, uint32_t B, uint64_t M, const uint32_t* __restrict__ ready, uint32_t epoch, const double* __restrict__ y,
     TileDst dst, uint32_t* __restrict__ fail) {
     __shared__ uint32_t ok;
     for (uint32_t bin = blockIdx.x; bin < B; bin += gridDim.x) {
@@ -464,7 +485,7 @@ __global__ __launch_bounds__(PUSH_THREADS) void pb_push_kernel(
         }
         __syncthreads();
         if (!ok) { if (threadIdx.x == 0) atomicExch(fail, 1u); return; }
-        const uint64_t r0 = (uint64_t)bin * R, r1 = min(r0 + R, M);
+        const uint64_t r0 = bm.row0(bin), r1 = min(r0 + bm.height(bin), M);
         // 16-byte accesses; y and the peers' vectors share their alignment (same row offset from 256-B aligned bases):
         // peel one row when the rank's first row is odd
         const uint64_t head = ((uintptr_t)(y + r0) & 15) ? 1 : 0;
@@ -571,6 +592,12 @@ void freeTilesWorkspace() {
     (void)hipSetDevice(keep);
 }
 
+static bool     g_taper = false;
+int setTilesTaper(int on) { g_taper = on != 0; return EXIT_SUCCESS; }
+uint64_t tilesBinRow(const DevMat* d, uint32_t bin) {
+    if (!d->tiles) return 0;
+    return bin >= d->tiles->B ? d->M : std::min<uint64_t>(d->M, d->tiles->bins.row0(bin));
+}
 static uint32_t g_rowsPerBin = 0;                  // 0 = automatic
 int setTilesRowsPerBin(uint32_t rows) {
     if (rows != 0 && (rows < 64 || rows > PB_R_MAX)) return EXIT_FAILURE;
@@ -611,8 +638,26 @@ int buildTiles(DevMat* d) {
     }
     if (g_rowsPerBin) R = g_rowsPerBin;                                                              // spmvHipSetTilesRowsPerBin
     if (const char* e = getenv("SPMV_PB_ROWS")) { const int v = atoi(e); if (v >= 64 && v <= (int)PB_R_MAX) R = (uint32_t)v; }   // tuning only
-    t->R = R;
-    t->B = (uint32_t)((M + R - 1) / R);
+    t->bins = BinMap{};
+    t->bins.c = R;
+    bool taper = g_taper;
+    if (const char* e = getenv("SPMV_PB_TAPER")) taper = atoi(e) != 0;                                 // tuning only
+    if (taper && M >= (uint64_t)4 * PB_CUS * 1024) {
+        // one round of quarter-height bins first and last, full-height bins (a multiple of PB_CUS of them) between
+        const uint32_t low = std::max<uint32_t>(64, (R / 4 + 63) / 64 * 64);
+        const uint64_t mid = M - (uint64_t)2 * PB_CUS * low;
+        const uint64_t nb = ((mid + PB_R_MAX - 1) / PB_R_MAX + PB_CUS - 1) / PB_CUS * PB_CUS;
+        const uint32_t high = std::min<uint32_t>(PB_R_MAX, (uint32_t)(((mid + nb - 1) / nb + 63) / 64 * 64));
+        const uint64_t n2 = (mid + high - 1) / high;                       // the last full-height bin may reach into the low zone:
+        t->bins.n1 = PB_CUS; t->bins.a = low;                              // zone 3 simply starts where zone 2 ends
+        t->bins.n2 = (uint32_t)n2; t->bins.b = high;
+        t->bins.c = low;
+        t->bins.z1 = (uint64_t)PB_CUS * low;
+        t->bins.z2 = t->bins.z1 + n2 * high;
+        if (t->bins.z2 >= M) { t->bins.n2 = (uint32_t)((M - t->bins.z1 + high - 1) / high); t->bins.z2 = t->bins.z1 + (uint64_t)t->bins.n2 * high; }
+    }
+    t->R = t->bins.maxHeight();
+    t->B = t->bins.z2 >= M ? t->bins.n1 + t->bins.n2 : t->bins.n1 + t->bins.n2 + (uint32_t)((M - t->bins.z2 + t->bins.c - 1) / t->bins.c);
     t->nnz = nnz;
     const uint64_t nTiles = (uint64_t)t->S * t->B;
     if (nTiles >= (1ull << 32) - 2) { fprintf(stderr, "libspmvhip: tiles: too many tiles\n"); delete t; return EXIT_FAILURE; }
@@ -644,7 +689,7 @@ int buildTiles(DevMat* d) {
                                      perm.as<uint32_t>(), (size_t)nnz, 0, bits, (hipStream_t) nullptr));
 
     hipLaunchKernelGGL(pb_bounds_kernel, grid2d((nnz + 255) / 256, 256), dim3(256), 0, nullptr, nnz, perm.as<uint32_t>(),
-                       keysOut.as<uint16_t>(), rowOf.as<uint32_t>(), t->B, t->R, nTiles, tileStart.as<uint32_t>());
+                       keysOut.as<uint16_t>(), rowOf.as<uint32_t>(), t->B, t->bins, nTiles, tileStart.as<uint32_t>());
     PB_TRY(hipGetLastError());
     // bin-major view: tile lengths (bin-major) -> exclusive scans give every tile's bin-major start and its index
     // in the list of non-empty tiles
@@ -674,7 +719,7 @@ int buildTiles(DevMat* d) {
                            tileStart.as<uint32_t>(), lens.as<uint32_t>(), bmStart.as<uint32_t>(), listIdx.as<uint32_t>(), t->nList,
                            t->tl, t->binPos, binTile.as<uint32_t>());
         hipLaunchKernelGGL(pb_gather_kernel, grid2d((nnz + 255) / 256, 256), dim3(256), 0, nullptr, nnz, perm.as<uint32_t>(),
-                           keysOut.as<uint16_t>(), rowOf.as<uint32_t>(), d->JA, d->AS, t->S, t->B, t->R, tileStart.as<uint32_t>(),
+                           keysOut.as<uint16_t>(), rowOf.as<uint32_t>(), d->JA, d->AS, t->S, t->B, t->bins, tileStart.as<uint32_t>(),
                            bmStart.as<uint32_t>(), t->val, t->lcol, t->lrow);
         TempBuf dupCount;
         if (dupCount.alloc((size_t)t->B * P2_WAVES * 4)) return fail("run-count workspace");
@@ -820,10 +865,10 @@ int enqueueTilesReduce(DevMat* d, uint32_t binBegin, uint32_t binEnd, double* y,
     const TileSignal none{nullptr, 0};
     if (nExtra)
         hipLaunchKernelGGL(pb_reduce_kernel<1>, grid, dim3(PB_THREADS), (size_t)8 * t->R, stream,
-                           t->R, binBegin, binEnd, d->M, t->binPos, t->waveTile, t->tl, prod, t->lrow, y, dst, none);
+                           t->bins, binBegin, binEnd, d->M, t->binPos, t->waveTile, t->tl, prod, t->lrow, y, dst, none);
     else
         hipLaunchKernelGGL(pb_reduce_kernel<0>, grid, dim3(PB_THREADS), (size_t)8 * t->R, stream,
-                           t->R, binBegin, binEnd, d->M, t->binPos, t->waveTile, t->tl, prod, t->lrow, y, dst, none);
+                           t->bins, binBegin, binEnd, d->M, t->binPos, t->waveTile, t->tl, prod, t->lrow, y, dst, none);
     return hipGetLastError() == hipSuccess ? EXIT_SUCCESS : EXIT_FAILURE;
 }
 
@@ -847,10 +892,10 @@ int enqueueTilesReducePush(DevMat* d, double* y, int nExtra, double* const* extr
     for (int i = 0; i < nExtra; ++i) dst.p[i] = extra[i];
     const TileSignal sig{t->ready, epoch};
     if (hipEventRecord(evFork, stream) != hipSuccess || hipStreamWaitEvent(side, evFork, 0) != hipSuccess) return EXIT_FAILURE;
-    hipLaunchKernelGGL(pb_push_kernel, dim3(std::min<uint32_t>(PUSH_WGS, t->B)), dim3(PUSH_THREADS), 0, side, t->R, t->B, d->M, t->ready,
+    hipLaunchKernelGGL(pb_push_kernel, dim3(std::min<uint32_t>(PUSH_WGS, t->B)), dim3(PUSH_THREADS), 0, side, t->bins, t->B, d->M, t->ready,
                        epoch, y, dst, t->pushFail);
     hipLaunchKernelGGL(pb_reduce_kernel<2>, grid2d((uint64_t)((t->B + 7) / 8) * 8, PB_THREADS), dim3(PB_THREADS), (size_t)8 * t->R, stream,
-                       t->R, 0u, t->B, d->M, t->binPos, t->waveTile, t->tl, prod, t->lrow, y, TileDst{}, sig);
+                       t->bins, 0u, t->B, d->M, t->binPos, t->waveTile, t->tl, prod, t->lrow, y, TileDst{}, sig);
     if (hipEventRecord(evJoin, side) != hipSuccess) return EXIT_FAILURE;          // the caller joins (tilesPushJoin) when it needs y delivered
     return hipGetLastError() == hipSuccess ? EXIT_SUCCESS : EXIT_FAILURE;
 }

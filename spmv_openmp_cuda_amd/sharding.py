@@ -254,6 +254,13 @@ class PushSpMV:
                 raise RuntimeError("spmvHipTilesShape failed")
             self.rpb = int(rpb.value)
             self.ranges = bin_ranges(int(nb.value), pieces if mode == "push" else 1, unit)
+
+            def first_row(b):                       # bins need not be equally high (tapered formats)
+                r = C.c_ulong()
+                if api.lib.spmvHipTilesBinRow(C.byref(dm.handle), b, C.byref(r)):
+                    raise RuntimeError("spmvHipTilesBinRow failed")
+                return int(r.value)
+            self.range_rows = [(first_row(b0), first_row(b1)) for b0, b1 in self.ranges]
             self.n_extra, self.extra = px.extra_pointers(self.row0)
         self.pieces = len(self.ranges) if self.tiles else 1
 
@@ -276,9 +283,9 @@ class PushSpMV:
             elif self.mode == "pushk":
                 rc = rc or lib.hipSpMVTilesReducePush(h, self.y_own, self.n_extra, self.extra)
             else:
-                for b0, b1 in self.ranges:
+                for (b0, b1), (ra, rb) in zip(self.ranges, self.range_rows):
                     rc = rc or lib.hipSpMVTilesReduce(h, b0, b1, self.y_own, 0, None)
-                    self.px.push(self.row0 + b0 * self.rpb, self.row0 + min(b1 * self.rpb, self.rows))
+                    self.px.push(self.row0 + ra, self.row0 + rb)
         else:
             rc = api.SPMV_LAUNCHERS[self.launcher](h, self.x_ptr, self.cfg, self.y_own) if self.rows else 0
             self.px.push(self.row0, self.row0 + self.rows)

@@ -99,6 +99,67 @@ def test_push_exchange_shared_gpu(tmp_path, world):
         assert (tmp_path / f"rank{r}.txt").read_text() == "ok"
 
 
+def test_tapered_bins_single_process():
+    """tapered format (low bins in the first and last round, spmvHipSetTilesTaper): same y, consistent bin -> row map"""
+    import ctypes as C
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from conftest import Oracle
+    from spmv_openmp_cuda_amd import api, synth
+    api.spmvHipInit(0)
+    api.lib.spmvHipSetStream(None)
+    api.lib.spmvHipSetSync(1)
+    oracle = Oracle()
+    w = synth.Workload("p", 2_400_011, 12_000_000, "powerlaw", 20000, 9)
+    lens = synth.row_lengths(w)
+    irp = synth.prefix(lens)
+    x_host = synth.make_x(w.N, w.cfg)
+    ja, as_ = oracle.synth_fill(w.N, 0, irp, synth.SEED_STRUCT + w.cfg, synth.SEED_VAL + w.cfg, 0)
+    y_ref = oracle.csr_serial_dev(irp.astype(np.uint32), ja, as_, x_host)
+    scale = np.add.reduceat(np.abs(as_ * x_host[ja]), irp[:-1].astype(np.int64))
+    dx = api.DeviceVector(w.N).up(x_host)
+    assert api.lib.spmvHipSetTilesTaper(1) == 0
+    try:
+        dm = synth.device_csr(w, irp, 0, w.N)
+        nb, rpb = C.c_uint(), C.c_uint()
+        assert api.lib.spmvHipTilesShape(C.byref(dm.handle), C.byref(nb), C.byref(rpb)) == 0
+    finally:
+        api.lib.spmvHipSetTilesTaper(0)
+    rows = []
+    for b in range(nb.value + 1):
+        r = C.c_ulong()
+        assert api.lib.spmvHipTilesBinRow(C.byref(dm.handle), b, C.byref(r)) == 0
+        rows.append(int(r.value))
+    h = np.diff(rows)
+    assert rows[0] == 0 and rows[-1] == w.N and (h > 0).all() and h.max() <= rpb.value
+    assert h[0] < h[len(h) // 2] and h[-2] < h[len(h) // 2]            # low bins at both ends, high bins between
+    assert (h[:256] == h[0]).all()                                     # one full round of low bins first
+    dy = api.DeviceVector(w.N)
+    dy.poison()
+    api.spmv("hipSpMVTilesCSR", dm, dx, dy)
+    y = dy.down()
+    assert not np.isnan(y).any() and np.all(np.abs(y - y_ref) <= 1e-13 * scale + 1e-300)
+    # the split launches on a tapered format: bin ranges in any order, fused store and push kernel
+    scratch = api.DeviceVector(w.N)
+    extra = (C.c_void_p * 1)(scratch.ptr.value)
+    from spmv_openmp_cuda_amd.sharding import bin_ranges
+    for mode in ("ranges", "fused", "pushk"):
+        dy.poison(); scratch.poison()
+        assert api.lib.hipSpMVTilesExpand(C.byref(dm.handle), dx.ptr) == 0
+        if mode == "ranges":
+            for b0, b1 in reversed(bin_ranges(nb.value, 3, 256)):
+                assert api.lib.hipSpMVTilesReduce(C.byref(dm.handle), b0, b1, dy.ptr, 0, None) == 0
+        elif mode == "fused":
+            assert api.lib.hipSpMVTilesReduce(C.byref(dm.handle), 0, nb.value, dy.ptr, 1, extra) == 0
+        else:
+            assert api.lib.hipSpMVTilesReducePush(C.byref(dm.handle), dy.ptr, 1, extra) == 0
+            assert api.lib.spmvHipTilesPushFailed(C.byref(dm.handle)) == 0
+        y2 = dy.down()
+        assert not np.isnan(y2).any() and np.all(np.abs(y2 - y_ref) <= 1e-13 * scale + 1e-300), mode
+        if mode != "ranges":
+            assert np.array_equal(scratch.down(), y2), mode
+    dm.free()
+
+
 def test_tiles_reduce_bin_ranges_single_process():
     """phase 2 cut into bin ranges == the one-launch result (same kernel, same order inside a bin up to atomics)"""
     import ctypes as C
