@@ -568,6 +568,12 @@ def main():
         if px is not None and args.exchange in ("auto", "auto-no-rccl", "push"):
             for q in ([args.pieces] if args.pieces > 0 else ([1, 2, 4, 8] if launcher == "hipSpMVTilesCSR" else [1])):
                 yield (lambda q=q: PushExchange(px, "push", q))
+        if px is not None and args.exchange in ("auto", "auto-no-rccl", "push") and world > 1 and args.pieces <= 0:
+            # copy engines + row groups: the rows of one group travel while the next group is computed.  On the PCIe
+            # stand-in (scripts/slowlink_groups.py) ONLY the copy engines overlap a transfer with the next group's
+            # kernels; stores issued by CUs (push kernel, fused store) to a slow destination hold those kernels up.
+            for q, G in ((1, 2), (1, 4), (2, 2)):
+                yield (lambda q=q, G=G: PushExchange(px, "push", q, G))
         # the fused store is tried only after a copy-engine push through the same mappings delivered a correct y
         if px is not None and args.exchange in ("auto", "auto-no-rccl", "fused") and launcher == "hipSpMVTilesCSR" and \
                 (args.exchange == "fused" or any(k.startswith("push") for k in exchange_ms)):

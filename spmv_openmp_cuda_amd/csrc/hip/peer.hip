@@ -95,7 +95,7 @@ int spmvHipPeerPush(const void* dSrcBase, size_t offset, size_t bytes, int nPeer
     for (int k = 0; k < nPeers; ++k) {
         HIP_TRY(hipStreamWaitEvent(P.stream[k], P.fence, 0));
         HIP_TRY(hipMemcpyAsync(static_cast<char*>(dPeerBases[k]) + offset, static_cast<const char*>(dSrcBase) + offset, bytes,
-                               hipMemcpyDeviceToDevice, P.stream[k]));
+                               hipMemcpyDefault, P.stream[k]));
         HIP_TRY(hipEventRecord(P.done[k], P.stream[k]));
         P.dirty[k] = true;
     }
