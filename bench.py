@@ -574,6 +574,11 @@ def main():
             # kernels; stores issued by CUs (push kernel, fused store) to a slow destination hold those kernels up.
             for q, G in ((1, 2), (1, 4), (2, 2)):
                 yield (lambda q=q, G=G: PushExchange(px, "push", q, G))
+            if launcher == "hipSpMVTilesCSR":
+                # tapered bins + copy engines, one group: the low first round leaves early, the low last round is the
+                # only part of y still to be sent when phase 2 ends, and phase 2 itself never waits for a link
+                yield (lambda: PushExchange(px, "push", 4, 1, 1, True))
+                yield (lambda: PushExchange(px, "push", 4, 2, 1, True))
         # the fused store is tried only after a copy-engine push through the same mappings delivered a correct y
         if px is not None and args.exchange in ("auto", "auto-no-rccl", "fused") and launcher == "hipSpMVTilesCSR" and \
                 (args.exchange == "fused" or any(k.startswith("push") for k in exchange_ms)):

@@ -85,7 +85,11 @@ _sigs = {
 IPC_HANDLE_BYTES = 64
 MAX_PEERS = 15
 for _name, (_args, _res) in _sigs.items():
-    _f = getattr(lib, _name)
+    _f = getattr(lib, _name, None)
+    if _f is None and os.environ.get("SPMV_LIB"):        # an older tuning build for an A/B may lack the newest entry points
+        continue
+    if _f is None:
+        raise SpmvHipError(f"{LIB_PATH} does not export {_name}: rebuild it (`make lib`)")
     _f.argtypes, _f.restype = _args, _res
 
 _hsigs = {

@@ -216,7 +216,7 @@ def test_tiles_reduce_bin_ranges_single_process():
     dm.free()
 
 
-@pytest.mark.parametrize("world,launcher", [(2, "auto"), (3, "hipSpMVWarpPerRowCSR")])
+@pytest.mark.parametrize("world,launcher", [(2, "hipSpMVTilesCSR"), (3, "hipSpMVWarpPerRowCSR")])
 def test_bench_multirank_path_on_shared_gpu(world, launcher):
     """bench.py's N > 1 code end to end (plan, kernel pick + broadcast, exchange candidates through peer windows,
     cross-rank and oracle checks, the ONE JSON line) with `world` ranks sharing the GPU; timings mean nothing."""
@@ -234,5 +234,7 @@ def test_bench_multirank_path_on_shared_gpu(world, launcher):
     assert j["n_gpus"] == world and j["parity"]["ok"] and j["parity"]["all_ranks_hold_identical_y"]
     assert j["config"]["exchange"] in j["config"]["exchange_step_ms"] and not j["config"]["exchange_rejected"]
     assert any(k.startswith("push") for k in j["config"]["exchange_step_ms"])
-    if launcher == "auto":
-        assert "fused" in j["config"]["exchange_step_ms"] or j["config"]["kernel"] != "hipSpMVTilesCSR"
+    if launcher == "hipSpMVTilesCSR":                    # every exchange family ran and delivered a complete y
+        for fam in ("fused", "pushk", "fused-g2", "pushk-g2", "fused-r2", "fused-t", "push-p1-g2"):
+            assert fam in j["config"]["exchange_step_ms"], fam
+        assert any(k.endswith("-t") and k.startswith("push-p") for k in j["config"]["exchange_step_ms"])
