@@ -572,7 +572,7 @@ def main():
             # copy engines + row groups: the rows of one group travel while the next group is computed.  On the PCIe
             # stand-in (scripts/slowlink_groups.py) ONLY the copy engines overlap a transfer with the next group's
             # kernels; stores issued by CUs (push kernel, fused store) to a slow destination hold those kernels up.
-            for q, G in ((1, 2), (1, 4), (2, 2)):
+            for q, G in ((1, 2), (1, 4), (2, 2)) + (((1, 8),) if world == 2 else ()):   # N = 2: one link carries half of y
                 yield (lambda q=q, G=G: PushExchange(px, "push", q, G))
             if launcher == "hipSpMVTilesCSR":
                 # tapered bins + copy engines, one group: the low first round leaves early, the low last round is the
