@@ -117,6 +117,22 @@ SPMV_HIP hipSpMVTilesCSR;
 int    spmvHipBuildTiles(spmat* dMat);
 size_t spmvHipTilesBytes(spmat* dMat);
 
+/* One-pass SpMV with y bins in LDS and x served by the XCD's L2: rows are cut into
+ * bins of <= 20 000 consecutive rows with equal entry counts, a workgroup owns a bin, and inside a bin the
+ * entries are stored in COLUMN order, so that the workgroups resident on one XCD sweep x together and gather
+ * from its L2.  12 B/nnz of streaming (fp64 value + {17-bit column offset, 15-bit local row}) and no second
+ * pass -- the intent of cudaSpMVWarpPerRowCSR (src/SpMV_CUDA.cu:52-73: coalesced AS/JA, gathered x, on-chip
+ * reduction) with the reduction in LDS accumulators.  The copy of the matrix (+12 B/nnz of device memory)
+ * is built on the device at the first call or with spmvHipBuildStripes.  Pays off while x (N * 8 B) is small
+ * against the entry stream; very wide matrices are the two-phase kernel's.  Row sums are added in arrival
+ * order (LDS atomics): equal to the oracle to rounding, not bitwise. */
+SPMV_HIP hipSpMVStripesCSR;
+int    spmvHipBuildStripes(spmat* dMat);
+size_t spmvHipStripesBytes(spmat* dMat);
+/* shape of the built format (zeros before the build): bins, rows of the highest bin, 1 if the 14 B/nnz
+ * encoding with 32-bit columns had to be used, device time of the one-time build in ms */
+int    spmvHipStripesShape(spmat* dMat, unsigned* nBins, unsigned* rowsPerBin, int* wide, double* buildMs);
+
 /* SELL-C-sigma (C = 64 rows per slice = one wavefront, rows sorted by length inside 16 Ki-row
  * windows, column-major inside a slice) built on the device from an uploaded CSR handle at the
  * first call: the ELL-family kernel for matrices whose longest row makes plain ELL impossible

@@ -1,0 +1,81 @@
+#!/usr/bin/env python3
+"""Kernel time (HIP events) of several launchers on one synthetic workload, same matrix, same x:
+    python3 scripts/time_launchers.py c3 hipSpMVTilesCSR hipSpMVStripesCSR [--steps 20] [--check]
+--check compares head / middle / tail 200 k-row windows of every launcher's y with the serial oracle."""
+import argparse
+import ctypes as C
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    p = argparse.ArgumentParser()
+    p.add_argument("workload")
+    p.add_argument("launchers", nargs="+")
+    p.add_argument("--steps", type=int, default=20)
+    p.add_argument("--scale", type=float, default=1.0)
+    p.add_argument("--check", action="store_true")
+    a = p.parse_args()
+    import numpy as np
+    import torch
+    from spmv_openmp_cuda_amd import api, synth
+    import bench
+    torch.cuda.set_device(0)
+    api.spmvHipInit(0)
+    api.lib.spmvHipSetStream(C.c_void_p(torch.cuda.current_stream().cuda_stream))
+    api.lib.spmvHipSetSync(0)
+    w = synth.WORKLOADS[a.workload]
+    if a.scale != 1.0:
+        w = synth.scaled(w, a.scale)
+    lens = synth.row_lengths(w)
+    irp = synth.prefix(lens)
+    dm = synth.device_csr(w, irp, 0, w.N)
+    x_host = synth.make_x(w.N, w.cfg)
+    x = torch.from_numpy(x_host).cuda()
+    y = torch.empty(w.N, dtype=torch.float64, device="cuda")
+    nnz = int(irp[-1])
+    alg = synth.algorithmic_bytes_csr(nnz, w.N, w.N)
+    cfg = api.CONFIG()
+    for name in a.launchers:
+        fn = api.SPMV_LAUNCHERS[name]
+        y.fill_(float("nan"))
+        if fn(C.byref(dm.handle), x.data_ptr(), cfg, y.data_ptr()):
+            print(f"{w.name} {name}: FAILED")
+            continue
+        torch.cuda.synchronize()
+        extra = ""
+        if name == "hipSpMVStripesCSR":
+            nb, rpb, wide, ms = C.c_uint(), C.c_uint(), C.c_int(), C.c_double()
+            api.lib.spmvHipStripesShape(C.byref(dm.handle), C.byref(nb), C.byref(rpb), C.byref(wide), C.byref(ms))
+            extra = f" bins={nb.value} rows/bin<={rpb.value} wide={wide.value} build={ms.value:.1f}ms"
+        if a.check:
+            spot = bench.oracle_spot_checks(synth, w, irp, x_host, lambda r0, r1: y[r0:r1].cpu().numpy())
+            extra += " check=" + ("ok" if all(not c["nan"] and c["max_abs_diff"] <= 1e-12 for c in spot) else "FAIL " + str(spot))
+        for _ in range(3):
+            fn(C.byref(dm.handle), x.data_ptr(), cfg, y.data_ptr())
+        evs = [(C.c_void_p(), C.c_void_p()) for _ in range(a.steps)]
+        for e0, e1 in evs:
+            api.lib.spmvHipEventCreate(C.byref(e0))
+            api.lib.spmvHipEventCreate(C.byref(e1))
+        torch.cuda.synchronize()
+        for e0, e1 in evs:
+            api.lib.spmvHipEventRecord(e0)
+            fn(C.byref(dm.handle), x.data_ptr(), cfg, y.data_ptr())
+            api.lib.spmvHipEventRecord(e1)
+        torch.cuda.synchronize()
+        ms = bench.kernel_ms(api, evs)
+        for e0, e1 in evs:
+            api.lib.spmvHipEventDestroy(e0)
+            api.lib.spmvHipEventDestroy(e1)
+        avg = sum(ms) / len(ms)
+        print(f"{w.name} {name}: avg {avg:.4f} ms  min {min(ms):.4f}  max {max(ms):.4f}  = {alg / avg / 8e9 * 100:.1f}% of 8 TB/s "
+              f"({2 * nnz / avg * 1e-6:.0f} GFLOP/s){extra}", flush=True)
+    dm.free()
+    api.spmvHipFinalize()
+
+
+if __name__ == "__main__":
+    main()

@@ -57,6 +57,9 @@ _sigs = {
     "spmvHipSellBytes": ([C.POINTER(spmat)], _sz),
     "hipSpMVTilesCSR": (_SPMV_ARGS, _i), "spmvHipBuildTiles": ([C.POINTER(spmat)], _i),
     "spmvHipTilesBytes": ([C.POINTER(spmat)], _sz),
+    "hipSpMVStripesCSR": (_SPMV_ARGS, _i), "spmvHipBuildStripes": ([C.POINTER(spmat)], _i),
+    "spmvHipStripesBytes": ([C.POINTER(spmat)], _sz),
+    "spmvHipStripesShape": ([C.POINTER(spmat), C.POINTER(C.c_uint), C.POINTER(C.c_uint), C.POINTER(_i), C.POINTER(C.c_double)], _i),
     "spmvHipEnqueueCSR": ([C.POINTER(spmat), _i, _vp, _vp, _vp], _i),
     "hipSpMVRowsELL": (_SPMV_ARGS, _i), "hipSpMVRowsELLNNTransposed": (_SPMV_ARGS, _i),
     "hipSpMVWarpsPerRowELLNTrasposed": (_SPMV_ARGS, _i),
@@ -116,6 +119,7 @@ SPMV_LAUNCHERS = {
     "hipSpMVRowsCSR": lib.hipSpMVRowsCSR,
     "hipSpMVWarpPerRowCSR": lib.hipSpMVWarpPerRowCSR,
     "hipSpMVTilesCSR": lib.hipSpMVTilesCSR,
+    "hipSpMVStripesCSR": lib.hipSpMVStripesCSR,
     "hipSpMVRowsSELL": lib.hipSpMVRowsSELL,
     "hipSpMVRowsELL": lib.hipSpMVRowsELL,
     "hipSpMVRowsELLNNTransposed": lib.hipSpMVRowsELLNNTransposed,

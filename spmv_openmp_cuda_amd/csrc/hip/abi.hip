@@ -125,6 +125,7 @@ void freeDesc(DevMat* d) {
     (void)hipFree(d->blkRow); (void)hipFree(d->blkInfo); (void)hipFree(d->blkBase);
     freeTiles(d->tiles);
     freeSell(d->sell);
+    freeStripes(d->stripes);
     d->magic = 0;
     delete d;
 }
@@ -627,6 +628,44 @@ int hipSpMVRowsSELL(spmat* dMat, double* dX, CONFIG cfg, double* dY) {
     Launch L(grid2d((d->M + 255) / 256, 256), dim3(256));
     if (enqueueSell(d, dX, dY, S.stream)) { ERR("hipSpMVRowsSELL: launch failed"); return EXIT_FAILURE; }
     return L.finish("hipSpMVRowsSELL");
+}
+
+int spmvHipBuildStripes(spmat* dMat) {
+    DevMat* d = descOf(dMat, "spmvHipBuildStripes");
+    if (!d) return EXIT_FAILURE;
+    if (d->kind != Kind::CSR) { ERR("spmvHipBuildStripes: handle is not CSR"); return EXIT_FAILURE; }
+    return buildStripes(d);
+}
+size_t spmvHipStripesBytes(spmat* dMat) {
+    DevMat* d = descOf(dMat, "spmvHipStripesBytes");
+    return d ? stripesBytes(d) : 0;
+}
+int spmvHipStripesShape(spmat* dMat, unsigned* nBins, unsigned* rowsPerBin, int* wide, double* buildMs) {
+    DevMat* d = descOf(dMat, "spmvHipStripesShape");
+    if (!d) return EXIT_FAILURE;
+    uint32_t b = 0, r = 0;
+    stripesShape(d, &b, &r, wide, buildMs);
+    if (nBins) *nBins = b;
+    if (rowsPerBin) *rowsPerBin = r;
+    return EXIT_SUCCESS;
+}
+int hipSpMVStripesCSR(spmat* dMat, double* dX, CONFIG cfg, double* dY) {
+    (void)cfg;
+    DevMat* d = descOf(dMat, "hipSpMVStripesCSR");
+    if (!d) return EXIT_FAILURE;
+    if (d->kind != Kind::CSR) { ERR("hipSpMVStripesCSR: handle is not CSR"); return EXIT_FAILURE; }
+    if (d->M == 0) return EXIT_SUCCESS;
+    if (d->NZ == 0) {                               // nothing to sweep: y = 0
+        HIP_TRY(hipMemsetAsync(dY, 0, d->M * sizeof(double), S.stream));
+        if (S.sync) HIP_TRY(hipStreamSynchronize(S.stream));
+        return EXIT_SUCCESS;
+    }
+    if (!d->stripes && buildStripes(d)) return EXIT_FAILURE;
+    uint32_t bins = 0, rowsPerBin = 0;
+    stripesShape(d, &bins, &rowsPerBin, nullptr, nullptr);
+    Launch L(dim3(bins), dim3(1024));
+    if (enqueueStripes(d, dX, dY, S.stream)) { ERR("hipSpMVStripesCSR: launch failed"); return EXIT_FAILURE; }
+    return L.finish("hipSpMVStripesCSR");
 }
 
 int hipSpMVTilesCSR(spmat* dMat, double* dX, CONFIG cfg, double* dY) {

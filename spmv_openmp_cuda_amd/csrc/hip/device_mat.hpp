@@ -33,6 +33,7 @@ enum class Kind : int { CSR = 0, ELL_ROWMAJOR = 1, ELL_COLMAJOR = 2 };
 
 struct TileFormat;          // column-sliced two-phase format, tiles.hip
 struct SellFormat;          // SELL-C-sigma, sell.hip
+struct StripeFormat;        // bin-wise CSC (y bins in LDS, x from the XCD's L2), stripes.hip
 
 struct DevMat {
     uint32_t magic = 0x53504D56;    // 'SPMV'
@@ -57,12 +58,19 @@ struct DevMat {
     uint32_t  nBlk2 = 0, nLong2 = 0;
     TileFormat* tiles = nullptr;    // built lazily by hipSpMVTilesCSR / spmvHipBuildTiles
     SellFormat* sell = nullptr;     // built lazily by hipSpMVRowsSELL / spmvHipBuildSell
+    StripeFormat* stripes = nullptr; // built lazily by hipSpMVStripesCSR / spmvHipBuildStripes
 };
 
 int  buildSell(DevMat* d);                                      // sell.hip
 void freeSell(SellFormat* f);
 int  enqueueSell(DevMat* d, const double* x, double* y, hipStream_t stream);
 size_t sellBytes(const DevMat* d);
+
+int  buildStripes(DevMat* d);                                   // stripes.hip
+void freeStripes(StripeFormat* f);
+int  enqueueStripes(DevMat* d, const double* x, double* y, hipStream_t stream);
+size_t stripesBytes(const DevMat* d);
+void stripesShape(const DevMat* d, uint32_t* bins, uint32_t* rowsPerBin, int* wide, double* buildMs);
 
 int  buildTiles(DevMat* d);                                     // tiles.hip
 void freeTiles(TileFormat* t);

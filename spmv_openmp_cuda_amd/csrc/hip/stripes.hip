@@ -1,0 +1,608 @@
+// stripes.hip -- one-pass SpMV with y bins in LDS and x served by the XCD's L2 ("bin-wise CSC").
+//
+// Why: on a matrix whose columns have no locality a row-major kernel pays one 128-B line per 8-byte x element
+// from the fabric (x lives beyond L2: <= 56 G gathers/s), and the two-phase kernel
+// (tiles.hip) buys streaming accesses with 16 extra bytes per entry (products out and back).  This kernel
+// keeps ONE pass of 12 B/nnz and moves the gather into L2 instead:
+//   * rows are cut into bins of <= 20 000 consecutive rows with (nearly) equal entry counts; a 1024-thread
+//     workgroup owns a bin and keeps its y in LDS (ds_add_f64);
+//   * inside a bin the entries are stored in COLUMN order.  Every workgroup therefore sweeps x from column 0
+//     to N-1 at the pace of its entry stream; the 32 workgroups resident on one XCD run the same sweep at the
+//     same average pace (equal entry counts), so a line of x fetched by the first of them is found in that
+//     XCD's 4 MiB L2 by the others: the gather is an L2 hit, and the column order lets neighbouring lanes
+//     share lines;
+//   * a step = 128 consecutive entries of a bin (two per lane): fp64 values and one 32-bit word per entry,
+//     {17-bit column offset from the step's first column, 15-bit local row}; the step's first column is a
+//     scalar load.  12.03 B/nnz.  A matrix with a step spanning >= 2^17 columns uses the WIDE encoding
+//     (32-bit column + 16-bit local row, 14 B/nnz) -- same kernel, other template argument.
+// HBM sees the 12 B/nnz stream, x once per round of bins and y once.  What bounds the kernel is the L2
+// request rate (one line per gather that shares its line with no neighbour) and, for very wide matrices, the
+// fabric: every XCD re-reads the lines of x its 32 bins touch in every round of bins, so the format pays off
+// while x (N * 8 B) is small against the entry stream (c3: 80 MB per XCD and round against 2.4 GB).
+//
+// Relation to the reference: the computation of cudaSpMVWarpPerRowCSR (src/SpMV_CUDA.cu:52-73) -- lanes
+// multiply entries of coalesced AS/JA spans with gathered x and the partial sums are reduced on chip -- with
+// the reduction moved from a shuffle tree per row to LDS accumulators per bin of rows, which is what allows
+// the column order.  Sums are added in arrival order: equal to the serial oracle to rounding, not bitwise.
+//
+// The format is built ON THE DEVICE from the device CSR (rocPRIM radix sort of (bin, column) keys).
+#include <hip/hip_runtime.h>
+#include <cstring>
+#include <rocprim/device/device_radix_sort.hpp>
+#include <algorithm>
+#include <vector>
+
+#include "spmvHip.h"
+#include "device_mat.hpp"
+
+namespace spmvhip {
+
+constexpr uint32_t SB_R_MAX   = 20000;              // rows per bin: <= 156.25 KiB of y in LDS
+#ifndef SPMV_SB_THREADS
+#define SPMV_SB_THREADS 512
+#endif
+constexpr int      SB_THREADS = SPMV_SB_THREADS;
+constexpr uint32_t SB_WAVES   = SB_THREADS / 64;
+constexpr uint32_t SB_STEP    = 128;                // entries per wavefront step (two per lane)
+constexpr uint32_t SB_ROWBITS = 15;
+constexpr uint32_t SB_NONE    = (1u << SB_ROWBITS) - 1;     // local row of a padding entry (SB_R_MAX < SB_NONE)
+constexpr uint32_t SB_DCOL_LIMIT = 1u << (32 - SB_ROWBITS);
+#ifndef SPMV_SB_DEPTH
+#define SPMV_SB_DEPTH 4
+#endif
+constexpr int      SB_DEPTH   = SPMV_SB_DEPTH;      // steps per register batch
+constexpr uint32_t SB_CUS     = 256;
+constexpr uint64_t SB_MIN_BIN_NNZ = 16384;          // do not cut a small matrix into bins shorter than this
+
+struct StripeFormat {
+    uint32_t  B = 0, R = 0;                         // bins, rows of the highest bin
+    uint64_t  nnz = 0, nSteps = 0;
+    bool      wide = false;
+    double*   val = nullptr;                        // [nSteps * 128] bin-major, column order inside a bin, bins padded to whole steps
+    uint32_t* cr = nullptr;                         // narrow: (column - stepBase) << 15 | local row;  wide: column
+    uint16_t* lrowW = nullptr;                      // wide only: local row
+    uint32_t* stepBase = nullptr;                   // narrow only: [nSteps] first column of the step
+    uint32_t* binRow = nullptr;                     // [B+1] first row of each bin
+    uint32_t* binStep = nullptr;                    // [B+1] first step of each bin
+    void*     sync = nullptr;                       // SbSync: progress slots of the workgroups, per XCD (zeroed before every launch)
+    uint32_t  ticketsPerBin = 0;                    // batches of the longest bin
+    size_t    bytes = 0;
+    double    buildMs = 0;
+};
+
+namespace {
+
+__device__ __forceinline__ uint64_t lin_block() { return (uint64_t)blockIdx.y * gridDim.x + blockIdx.x; }
+
+typedef double   dbl2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef uint16_t u16x2 __attribute__((ext_vector_type(2)));
+
+// ---- build kernels ---------------------------------------------------------------------------------------
+// key = bin << colBits | column, payload = CSR position; one wavefront per row
+template <typename I>
+__global__ __launch_bounds__(256) void sb_keys_kernel(uint64_t M, const I* __restrict__ IRP, const uint32_t* __restrict__ JA,
+                                                      const uint32_t* __restrict__ binRow, uint32_t B, unsigned colBits,
+                                                      uint64_t* __restrict__ keys, uint32_t* __restrict__ idx,
+                                                      uint32_t* __restrict__ rowOf) {
+    const uint64_t r = lin_block() * 4 + threadIdx.x / 64;
+    if (r >= M) return;
+    uint32_t lo = 0, hi = B;                         // bin with binRow[bin] <= r < binRow[bin + 1]
+    while (hi - lo > 1) {
+        const uint32_t mid = lo + (hi - lo) / 2;
+        if (binRow[mid] <= r) lo = mid; else hi = mid;
+    }
+    const uint64_t b = IRP[r], e = IRP[r + 1];
+    for (uint64_t j = b + threadIdx.x % 64; j < e; j += 64) {
+        keys[j] = (uint64_t)lo << colBits | JA[j];
+        idx[j] = (uint32_t)j;
+        rowOf[j] = (uint32_t)r;
+    }
+}
+
+// sorted position p -> padded position q of its bin; values, encoded columns / rows, step bases
+template <bool WIDE>
+__global__ __launch_bounds__(256) void sb_scatter_kernel(
+    uint64_t nnz, unsigned colBits, const uint64_t* __restrict__ skeys, const uint32_t* __restrict__ perm,
+    const uint32_t* __restrict__ rowOf, const double* __restrict__ AS, const uint32_t* __restrict__ binRow,
+    const uint64_t* __restrict__ binStart, const uint32_t* __restrict__ binStep,
+    double* __restrict__ val, uint32_t* __restrict__ cr, uint16_t* __restrict__ lrowW, uint32_t* __restrict__ stepBase,
+    uint32_t* __restrict__ overflow) {
+    const uint64_t p = lin_block() * 256 + threadIdx.x;
+    if (p >= nnz) return;
+    const uint64_t key = skeys[p];
+    const uint32_t bin = (uint32_t)(key >> colBits);
+    const uint32_t col = (uint32_t)(key & ((1ull << colBits) - 1));
+    const uint64_t pos = p - binStart[bin];
+    // inside a step the 128 column-ordered entries are dealt to the lanes as (e, 64 + e): lane l reads the pair at
+    // positions 2l, 2l + 1 with one 16-byte load, and each of the step's two gather instructions covers 64 NEIGHBOURING
+    // entries (lanes share lines inside an instruction; the two instructions touch different lines -- with (2l, 2l + 1)
+    // pairs the second gather hit lines still pending from the first and stalled the L1: TCP_PENDING_STALL_CYCLES)
+    const uint64_t e = pos % SB_STEP;
+    const uint64_t q = (uint64_t)binStep[bin] * SB_STEP + (pos - e) + (e < SB_STEP / 2 ? 2 * e : 2 * (e - SB_STEP / 2) + 1);
+    const uint32_t j = perm[p];
+    const uint32_t lrow = rowOf[j] - binRow[bin];
+    val[q] = AS[j];
+    if (WIDE) {
+        cr[q] = col;
+        lrowW[q] = (uint16_t)lrow;
+    } else {
+        const uint64_t inStep = e;
+        const uint32_t base = (uint32_t)(skeys[p - inStep] & ((1ull << colBits) - 1));
+        const uint32_t d = col - base;
+        if (d >= SB_DCOL_LIMIT) atomicOr(overflow, 1u);
+        cr[q] = d << SB_ROWBITS | lrow;
+        if (inStep == 0) stepBase[q / SB_STEP] = base;
+    }
+}
+
+__global__ __launch_bounds__(256) void sb_fill32_kernel(uint32_t* __restrict__ p, uint64_t n, uint32_t v) {
+    const uint64_t i = lin_block() * 256 + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+__global__ __launch_bounds__(256) void sb_fill16_kernel(uint16_t* __restrict__ p, uint64_t n, uint16_t v) {
+    const uint64_t i = lin_block() * 256 + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+
+// ---- the SpMV kernel -------------------------------------------------------------------------------------
+// A batch = SB_DEPTH consecutive steps of the bin.  Batches are handed to the 16 wavefronts of the bin's workgroup
+// through a ticket counter in LDS, NOT by a fixed wavefront -> batch map: the scheduler favours the oldest
+// wavefront of a workgroup, and with a fixed map wavefront 0 finished its share after a quarter of the bin's time
+// while the youngest needed all of it -- sixteen sweeps of x at sixteen different places, and the L2 kept none of
+// them (c3: 52 % hits, 10 GB fetched for 2.6 GB; profiles/r02_stripes.md).  With tickets the workgroup has ONE
+// frontier: a faster wavefront simply takes more batches.
+// Three stages per batch -- stream loads (values, column/row words; non-temporal), x gathers, LDS adds -- are kept
+// apart by TWO batches of stream loads: vmcnt counts in issue order, so a gather may only be waited for while
+// younger stream loads are outstanding if those were issued AFTER it.  Issue order of iteration k:
+//     gather(k+1) [needs stream(k+1), issued two iterations ago], stream(k+3), add(k) [needs gather(k)]
+// Four stream batches and two gather batches rotate through registers (the loop body is written out four times
+// so that every batch is a named register set).  Steps past the bin's end are clamped to its last step (a valid,
+// cached address) and skipped when adding: no branch around a load, the compiler's vmcnt stays exact.
+struct SbStream { dbl2 v[SB_DEPTH]; u32x2 c[SB_DEPTH]; u16x2 r[SB_DEPTH]; uint32_t base[SB_DEPTH]; uint32_t first; };
+struct SbGather { double x0[SB_DEPTH], x1[SB_DEPTH]; };
+
+// stream loads of the batch with ticket `t` (wavefront-uniform): steps s0 + t * SB_DEPTH + u
+template <bool WIDE>
+__device__ __forceinline__ void sb_stream(SbStream& s, uint32_t t, uint32_t s0, uint32_t s1, uint32_t lane,
+                                          const double* __restrict__ val, const uint32_t* __restrict__ cr,
+                                          const uint16_t* __restrict__ lrowW, const uint32_t* __restrict__ stepBase) {
+    s.first = s0 + t * SB_DEPTH;
+#pragma unroll
+    for (int u = 0; u < SB_DEPTH; ++u) {
+        const uint32_t sc = min(s.first + u, s1 - 1u);
+        const uint64_t q = (uint64_t)sc * SB_STEP + 2u * lane;
+        s.v[u] = __builtin_nontemporal_load((const dbl2*)(val + q));
+        s.c[u] = __builtin_nontemporal_load((const u32x2*)(cr + q));
+        if (WIDE) { s.r[u] = __builtin_nontemporal_load((const u16x2*)(lrowW + q)); s.base[u] = 0; }
+        else      { s.base[u] = stepBase[sc]; s.r[u] = u16x2{0, 0}; }
+    }
+}
+
+#ifndef SPMV_SB_GATHER
+#define SPMV_SB_GATHER 0
+#endif
+__device__ __forceinline__ double sb_ldx(const double* p) {      // tuning: cache policy of the x gather
+#if SPMV_SB_GATHER == 1
+    return __builtin_nontemporal_load(p);
+#elif SPMV_SB_GATHER == 2
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#else
+    return *p;
+#endif
+}
+
+template <bool WIDE>
+__device__ __forceinline__ void sb_gather(SbGather& g, const SbStream& s, const double* __restrict__ x) {
+#pragma unroll
+    for (int u = 0; u < SB_DEPTH; ++u) {
+        const uint32_t c0 = WIDE ? s.c[u].x : s.base[u] + (s.c[u].x >> SB_ROWBITS);
+        const uint32_t c1 = WIDE ? s.c[u].y : s.base[u] + (s.c[u].y >> SB_ROWBITS);
+        g.x0[u] = sb_ldx(x + c0);
+        g.x1[u] = sb_ldx(x + c1);
+    }
+}
+
+template <bool WIDE>
+__device__ __forceinline__ void sb_add(double* yb, const SbStream& s, const SbGather& g, uint32_t s1) {
+#pragma unroll
+    for (int u = 0; u < SB_DEPTH; ++u) {
+        const uint32_t r0 = WIDE ? s.r[u].x : s.c[u].x & SB_NONE;
+        const uint32_t r1 = WIDE ? s.r[u].y : s.c[u].y & SB_NONE;
+        if (s.first + u < s1) {                      // wavefront-uniform
+            if (r0 != SB_NONE) atomicAdd(&yb[r0], s.v[u].x * g.x0[u]);
+            if (r1 != SB_NONE) atomicAdd(&yb[r1], s.v[u].y * g.x1[u]);
+        }
+    }
+}
+
+// ---- keeping the workgroups of one XCD together -------------------------------------------------------------
+// The gather is an L2 hit only while the workgroups resident on one XCD stay within ~1-2 MB of x of each other
+// (4 MiB of L2 minus what the wavefronts' own loads in flight span).  Equal entry counts per bin give equal
+// AVERAGE speeds, but a workgroup that falls behind the others finds its lines evicted, runs slower still and
+// never comes back; and a second round of bins started as the first round's workgroups ended, 50-90 us apart.
+// So the kernel is persistent (one workgroup per CU walks the bins w, w + G, ...: every round starts where the
+// last one ended) and the workgroups of an XCD throttle their LEADERS: each publishes its progress -- tickets
+// handed out so far, counted over all of its bins -- in a slot of a per-XCD line of global memory, and a
+// wavefront whose new ticket is more than `window` ahead of the XCD's slowest workgroup sleeps until that one
+// has caught up.  The slowest workgroup never waits, workgroups register when they start (one not yet resident
+// is not waited for) and mark their slot done when they leave, and a wait that exceeds its spin budget switches
+// the throttle off for that workgroup: the protocol changes speed, never results, and cannot hang.
+// State is zeroed by a memset node in front of every launch.
+struct SbSync { uint32_t count[8]; uint32_t pad[8]; uint32_t prog[8 * 64]; };
+constexpr uint32_t SB_SYNC_OFF = 0xFFFFFFFFu;
+constexpr uint32_t SB_SPIN_BUDGET = 1u << 14;       // sleeps of ~0.4 us: a few ms in total, then the workgroup stops throttling
+
+struct SbLds { uint32_t ctr, lim, slot, budget; };   // behind the bin's y in LDS
+
+__device__ __forceinline__ uint32_t sb_wave_min(uint32_t v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = min(v, (uint32_t)__shfl_xor((int)v, off, 64));
+    return v;
+}
+
+// next ticket of the workgroup (one LDS atomic by lane 0, broadcast); publishes the progress and waits while the
+// ticket is more than `window` ahead of the XCD's slowest workgroup
+__device__ __forceinline__ uint32_t sb_ticket(SbLds* l, uint32_t lane, SbSync* sync, uint32_t p0, uint32_t window) {
+    uint32_t t = 0;
+    if (lane == 0) t = atomicAdd(&l->ctr, 1u);
+    t = (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
+    const uint32_t slot = (uint32_t)__builtin_amdgcn_readfirstlane((int)l->slot);
+    if (slot != SB_SYNC_OFF) {                       // wavefront-uniform
+        const uint32_t P = p0 + t;
+        if (lane == 0) __hip_atomic_store(&sync->prog[slot], P, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        uint32_t lim = (uint32_t)__builtin_amdgcn_readfirstlane((int)l->lim);
+        if (P > lim) {
+            const uint32_t xcc = slot / 64;
+            uint32_t spins = 0;
+            for (;;) {
+                const uint32_t cnt = __hip_atomic_load(&sync->count[xcc], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                uint32_t v = __hip_atomic_load(&sync->prog[xcc * 64 + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (lane >= cnt) v = SB_SYNC_OFF;
+                const uint32_t m = sb_wave_min(v);
+                lim = m > SB_SYNC_OFF - window ? SB_SYNC_OFF : m + window;
+                if (lane == 0) l->lim = lim;
+                if (P <= lim) break;
+                if (++spins >= 64) {                 // long wait: charge the workgroup's budget, give up when it is spent
+                    spins = 0;
+                    uint32_t left = 0;
+                    if (lane == 0) left = atomicSub(&l->budget, 64u);
+                    left = (uint32_t)__builtin_amdgcn_readfirstlane((int)left);
+                    if (left <= 64u || left > SB_SPIN_BUDGET) {
+                        if (lane == 0) { l->slot = SB_SYNC_OFF; __hip_atomic_store(&sync->prog[slot], SB_SYNC_OFF, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+                        break;
+                    }
+                }
+                __builtin_amdgcn_s_sleep(16);
+            }
+        }
+    }
+    return t;
+}
+
+#ifdef SPMV_SB_DEBUG          // tuning builds only: per-bin placement and progress stamps (100 MHz clock)
+__device__ uint64_t sb_dbg[8 * 8192];
+__device__ __forceinline__ uint64_t sb_now() { return __builtin_amdgcn_s_memrealtime(); }
+#define SB_STAMP(slot) do { if (bin < 8192) sb_dbg[bin * 8 + (slot)] = sb_now(); } while (0)
+#endif
+
+template <bool WIDE>
+__global__ __launch_bounds__(SB_THREADS) void sb_spmv_kernel(
+    uint32_t B, const uint32_t* __restrict__ binRow, const uint32_t* __restrict__ binStep,
+    const double* __restrict__ val, const uint32_t* __restrict__ cr, const uint16_t* __restrict__ lrowW,
+    const uint32_t* __restrict__ stepBase, const double* __restrict__ x, double* __restrict__ y, uint32_t ldsRows,
+    SbSync* sync, uint32_t window, uint32_t ticketsPerBin) {
+    extern __shared__ double yb[];                  // ldsRows doubles (rows of the highest bin), then SbLds
+    SbLds* l = reinterpret_cast<SbLds*>(yb + ldsRows);
+    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x / 64)), lane = threadIdx.x % 64;
+    if (threadIdx.x == 0) {
+        uint32_t slot = SB_SYNC_OFF;
+        if (sync) {                                  // register with the workgroups of this XCD
+            uint32_t xcc;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+            xcc &= 7u;
+            const uint32_t k = atomicAdd(&sync->count[xcc], 1u);
+            if (k < 64) slot = xcc * 64 + k;
+        }
+        l->slot = slot;
+        l->lim = window;
+        l->budget = SB_SPIN_BUDGET;
+    }
+    uint32_t p0 = 0;                                 // tickets of this workgroup's earlier bins
+    for (uint64_t bin = lin_block(); bin < B; bin += (uint64_t)gridDim.x * gridDim.y, p0 += ticketsPerBin) {
+        const uint32_t row0 = binRow[bin], R = binRow[bin + 1] - row0;
+        const uint32_t s0 = binStep[bin], s1 = binStep[bin + 1];
+#ifdef SPMV_SB_DEBUG
+        if (threadIdx.x == 0 && bin < 8192) {
+            uint32_t xcc, hwid;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+            sb_dbg[bin * 8 + 0] = (uint64_t)xcc << 32 | hwid;
+            SB_STAMP(1);
+        }
+#endif
+        SbStream a, b, c, d;
+        SbGather g0, g1;
+        if (s1 > s0) {                               // first three batches: tickets wave, wave + W, wave + 2 W; moving before the bin is zeroed
+            sb_stream<WIDE>(a, wave, s0, s1, lane, val, cr, lrowW, stepBase);
+            sb_stream<WIDE>(b, wave + SB_WAVES, s0, s1, lane, val, cr, lrowW, stepBase);
+            sb_stream<WIDE>(c, wave + 2 * SB_WAVES, s0, s1, lane, val, cr, lrowW, stepBase);
+        }
+        for (uint32_t k = threadIdx.x; k < R; k += SB_THREADS) yb[k] = 0.0;
+        if (threadIdx.x == 0) l->ctr = 3 * SB_WAVES;
+        __syncthreads();
+        if (s1 > s0) {
+            sb_gather<WIDE>(g0, a, x);
+#ifdef SPMV_SB_DEBUG
+            const uint32_t quarter = (s1 - s0) / 4;
+            uint32_t nextMark = 1;
+#define SB_PROGRESS(S) do { if (lane == 0 && nextMark < 4 && (S).first - s0 >= nextMark * quarter) { SB_STAMP(1 + nextMark); } \
+                            while (nextMark < 4 && (S).first - s0 >= nextMark * quarter) ++nextMark; } while (0)
+#else
+#define SB_PROGRESS(S) do { } while (0)
+#endif
+            // one stage: CUR is added, NXT gathered, FAR (the set CUR's predecessor freed) streamed with a fresh ticket
+#define SB_STAGE(CUR, NXT, FAR, GC, GN)                                                                          \
+            if (CUR.first >= s1) break;                                                                          \
+            sb_gather<WIDE>(GN, NXT, x);                                                                         \
+            sb_stream<WIDE>(FAR, sb_ticket(l, lane, sync, p0, window), s0, s1, lane, val, cr, lrowW, stepBase); \
+            sb_add<WIDE>(yb, CUR, GC, s1);                                                                       \
+            SB_PROGRESS(CUR);
+            for (;;) {
+                SB_STAGE(a, b, d, g0, g1)
+                SB_STAGE(b, c, a, g1, g0)
+                SB_STAGE(c, d, b, g0, g1)
+                SB_STAGE(d, a, c, g1, g0)
+            }
+#undef SB_STAGE
+#undef SB_PROGRESS
+        }
+        __syncthreads();
+#ifdef SPMV_SB_DEBUG
+        if (threadIdx.x == 0) SB_STAMP(5);
+#endif
+        for (uint32_t k = threadIdx.x; k < R; k += SB_THREADS) y[(uint64_t)row0 + k] = yb[k];
+        __syncthreads();                             // the next bin zeroes yb
+    }
+    if (threadIdx.x == 0 && l->slot != SB_SYNC_OFF)  // nobody waits for a workgroup that has left
+        __hip_atomic_store(&sync->prog[l->slot], SB_SYNC_OFF, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+#define SB_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { fprintf(stderr, "libspmvhip: stripes: %s: %s\n", #expr, hipGetErrorString(e_)); return EXIT_FAILURE; } } while (0)
+
+struct TempBuf {
+    void* p = nullptr;
+    ~TempBuf() { if (p) (void)hipFree(p); }
+    hipError_t alloc(size_t bytes) { return hipMalloc(&p, std::max<size_t>(bytes, 1)); }
+    template <typename T> T* as() { return static_cast<T*>(p); }
+};
+
+// Bins: consecutive rows, (nearly) equal entry counts, at most SB_R_MAX rows.  Equal counts are what keeps the
+// workgroups of one XCD at the same place of their column sweeps; the bin count is a multiple of the CU count
+// (one workgroup per CU at a time: bins run in rounds) once the matrix is large enough for a full round.
+bool planBins(const std::vector<uint64_t>& irp, uint64_t M, uint32_t rMax, std::vector<uint32_t>& binRow) {
+    const uint64_t nnz = irp[M];
+    uint64_t B = std::max<uint64_t>((M + rMax - 1) / rMax, std::min<uint64_t>(SB_CUS, (nnz + SB_MIN_BIN_NNZ - 1) / SB_MIN_BIN_NNZ));
+    B = std::max<uint64_t>(1, std::min<uint64_t>(B, M));
+    if (B > SB_CUS) B = (B + SB_CUS - 1) / SB_CUS * SB_CUS;
+    if (B > M) B = M;
+    if (B >= (1ull << 31)) return false;
+    binRow.assign(B + 1, 0);
+    uint64_t cur = 0;
+    for (uint64_t b = 0; b < B; ++b) {
+        const uint64_t left = B - b;                 // bins still to cut, this one included
+        uint64_t next;
+        if (left == 1) next = M;
+        else {
+            const uint64_t target = irp[cur] + (irp[M] - irp[cur] + left - 1) / left;
+            next = (uint64_t)(std::lower_bound(irp.begin() + cur, irp.begin() + M + 1, target) - irp.begin());
+            if (next > cur + 1 && target - irp[next - 1] < irp[next] - target) --next;     // the closer of the two cuts
+            next = std::max(next, cur + 1);                                              // at least one row
+            next = std::min(next, cur + rMax);                                           // y fits the LDS
+            next = std::min(next, M - (left - 1));                                       // one row for every later bin
+            const uint64_t cap = (left - 1) * (uint64_t)rMax;                            // ... and they can hold the rest
+            if (M - next > cap) next = M - cap;
+        }
+        cur = next;
+        binRow[b + 1] = (uint32_t)cur;
+    }
+    return cur == M;
+}
+
+}  // namespace
+
+void freeStripes(StripeFormat* f) {
+    if (!f) return;
+    (void)hipFree(f->val); (void)hipFree(f->cr); (void)hipFree(f->lrowW); (void)hipFree(f->stepBase);
+    (void)hipFree(f->binRow); (void)hipFree(f->binStep); (void)hipFree(f->sync);
+    delete f;
+}
+
+size_t stripesBytes(const DevMat* d) { return d->stripes ? d->stripes->bytes : 0; }
+
+void stripesShape(const DevMat* d, uint32_t* bins, uint32_t* rowsPerBin, int* wide, double* buildMs) {
+    const StripeFormat* f = d->stripes;
+    if (bins) *bins = f ? f->B : 0;
+    if (rowsPerBin) *rowsPerBin = f ? f->R : 0;
+    if (wide) *wide = f ? (f->wide ? 1 : 0) : 0;
+    if (buildMs) *buildMs = f ? f->buildMs : 0.0;
+}
+
+static int fillFormat(StripeFormat* f, bool wide, uint64_t nnz, unsigned colBits, const uint64_t* skeys, const uint32_t* perm,
+                      const uint32_t* rowOf, const double* AS, const uint64_t* dBinStart, uint32_t* dOverflow) {
+    const uint64_t cells = f->nSteps * SB_STEP;
+    f->wide = wide;
+    (void)hipFree(f->cr); (void)hipFree(f->lrowW); (void)hipFree(f->stepBase);
+    f->cr = nullptr; f->lrowW = nullptr; f->stepBase = nullptr;
+    if (!f->val) SB_TRY(hipMalloc(&f->val, std::max<uint64_t>(cells, 1) * 8));
+    SB_TRY(hipMalloc(&f->cr, std::max<uint64_t>(cells, 1) * 4));
+    if (wide) SB_TRY(hipMalloc(&f->lrowW, std::max<uint64_t>(cells, 1) * 2));
+    else      SB_TRY(hipMalloc(&f->stepBase, std::max<uint64_t>(f->nSteps, 1) * 4));
+    // padding entries: value 0, local row SB_NONE (skipped by the kernel: 0 * x must not turn an Inf/NaN of x into a NaN of y)
+    SB_TRY(hipMemsetAsync(f->val, 0, cells * 8, nullptr));
+    if (cells) {
+        if (wide) {
+            SB_TRY(hipMemsetAsync(f->cr, 0, cells * 4, nullptr));
+            hipLaunchKernelGGL(sb_fill16_kernel, grid2d((cells + 255) / 256, 256), dim3(256), 0, nullptr, f->lrowW, cells, (uint16_t)SB_NONE);
+        } else {
+            hipLaunchKernelGGL(sb_fill32_kernel, grid2d((cells + 255) / 256, 256), dim3(256), 0, nullptr, f->cr, cells, SB_NONE);
+            SB_TRY(hipMemsetAsync(f->stepBase, 0, f->nSteps * 4, nullptr));
+        }
+    }
+    SB_TRY(hipMemsetAsync(dOverflow, 0, 4, nullptr));
+    if (wide)
+        hipLaunchKernelGGL(sb_scatter_kernel<true>, grid2d((nnz + 255) / 256, 256), dim3(256), 0, nullptr, nnz, colBits, skeys, perm, rowOf, AS,
+                           f->binRow, dBinStart, f->binStep, f->val, f->cr, f->lrowW, f->stepBase, dOverflow);
+    else
+        hipLaunchKernelGGL(sb_scatter_kernel<false>, grid2d((nnz + 255) / 256, 256), dim3(256), 0, nullptr, nnz, colBits, skeys, perm, rowOf, AS,
+                           f->binRow, dBinStart, f->binStep, f->val, f->cr, f->lrowW, f->stepBase, dOverflow);
+    SB_TRY(hipGetLastError());
+    return EXIT_SUCCESS;
+}
+
+int buildStripes(DevMat* d) {
+    if (d->stripes) return EXIT_SUCCESS;
+    if (d->kind != Kind::CSR) return EXIT_FAILURE;
+    const uint64_t nnz = d->NZ, M = d->M, N = d->N;
+    if (nnz >= IRP32_LIMIT || nnz == 0 || M == 0) {
+        fprintf(stderr, "libspmvhip: stripes: nnz = %lu unsupported (needs 0 < nnz < 2^32)\n", (unsigned long)nnz);
+        return EXIT_FAILURE;
+    }
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    SB_TRY(hipEventCreate(&ev0));
+    SB_TRY(hipEventCreate(&ev1));
+    struct EvGuard { hipEvent_t a, b; ~EvGuard() { (void)hipEventDestroy(a); (void)hipEventDestroy(b); } } evGuard{ev0, ev1};
+    SB_TRY(hipEventRecord(ev0, nullptr));
+
+    // row pointers on the host (bins are cut there)
+    std::vector<uint64_t> irp(M + 1);
+    if (d->irpBytes == 8) SB_TRY(hipMemcpy(irp.data(), d->IRP, (M + 1) * 8, hipMemcpyDeviceToHost));
+    else {
+        std::vector<uint32_t> tmp(M + 1);
+        SB_TRY(hipMemcpy(tmp.data(), d->IRP, (M + 1) * 4, hipMemcpyDeviceToHost));
+        for (uint64_t i = 0; i <= M; ++i) irp[i] = tmp[i];
+    }
+    uint32_t rMax = SB_R_MAX;
+    if (const char* e = getenv("SPMV_SB_ROWS")) { const int v = atoi(e); if (v >= 1 && v <= (int)SB_R_MAX) rMax = (uint32_t)v; }     // tuning only
+    std::vector<uint32_t> binRow;
+    if (!planBins(irp, M, rMax, binRow)) { fprintf(stderr, "libspmvhip: stripes: cannot cut %lu rows into bins\n", (unsigned long)M); return EXIT_FAILURE; }
+    const uint32_t B = (uint32_t)binRow.size() - 1;
+    std::vector<uint64_t> binStart(B + 1);
+    std::vector<uint32_t> binStep(B + 1);
+    uint64_t steps = 0;
+    uint32_t R = 0;
+    for (uint32_t b = 0; b < B; ++b) {
+        binStart[b] = irp[binRow[b]];
+        binStep[b] = (uint32_t)steps;
+        steps += (irp[binRow[b + 1]] - irp[binRow[b]] + SB_STEP - 1) / SB_STEP;
+        R = std::max(R, binRow[b + 1] - binRow[b]);
+    }
+    binStart[B] = nnz;
+    if (steps >= (1ull << 32) - (1u << 16)) { fprintf(stderr, "libspmvhip: stripes: too many steps\n"); return EXIT_FAILURE; }
+    binStep[B] = (uint32_t)steps;
+    uint32_t maxBinSteps = 0;
+    for (uint32_t b = 0; b < B; ++b) maxBinSteps = std::max(maxBinSteps, binStep[b + 1] - binStep[b]);
+    { std::vector<uint64_t>().swap(irp); }
+
+    StripeFormat* f = new StripeFormat;
+    f->B = B; f->R = R; f->nnz = nnz; f->nSteps = steps;
+    f->ticketsPerBin = (maxBinSteps + SB_DEPTH - 1) / SB_DEPTH;
+    auto fail = [&](const char* what) { fprintf(stderr, "libspmvhip: stripes: %s failed\n", what); freeStripes(f); return EXIT_FAILURE; };
+    TempBuf keys, keysOut, idx, perm, rowOf, sortTmp, dBinStart, dOverflow;
+    if (hipMalloc(&f->binRow, ((size_t)B + 1) * 4) || hipMalloc(&f->binStep, ((size_t)B + 1) * 4) || dBinStart.alloc(((size_t)B + 1) * 8) ||
+        dOverflow.alloc(4) || hipMalloc(&f->sync, sizeof(SbSync)))
+        return fail("table allocation");
+    if (hipMemcpy(f->binRow, binRow.data(), ((size_t)B + 1) * 4, hipMemcpyHostToDevice) ||
+        hipMemcpy(f->binStep, binStep.data(), ((size_t)B + 1) * 4, hipMemcpyHostToDevice) ||
+        hipMemcpy(dBinStart.p, binStart.data(), ((size_t)B + 1) * 8, hipMemcpyHostToDevice))
+        return fail("table upload");
+    if (keys.alloc(nnz * 8) || keysOut.alloc(nnz * 8) || idx.alloc(nnz * 4) || perm.alloc(nnz * 4) || rowOf.alloc(nnz * 4))
+        return fail("temporary allocation");
+
+    unsigned colBits = 1, binBits = 1;
+    while (colBits < 32 && (1ull << colBits) < N) ++colBits;
+    while ((1ull << binBits) < B) ++binBits;
+    if (d->irpBytes == 4)
+        hipLaunchKernelGGL((sb_keys_kernel<uint32_t>), grid2d((M + 3) / 4, 256), dim3(256), 0, nullptr, M, static_cast<const uint32_t*>(d->IRP), d->JA,
+                           f->binRow, B, colBits, keys.as<uint64_t>(), idx.as<uint32_t>(), rowOf.as<uint32_t>());
+    else
+        hipLaunchKernelGGL((sb_keys_kernel<uint64_t>), grid2d((M + 3) / 4, 256), dim3(256), 0, nullptr, M, static_cast<const uint64_t*>(d->IRP), d->JA,
+                           f->binRow, B, colBits, keys.as<uint64_t>(), idx.as<uint32_t>(), rowOf.as<uint32_t>());
+    if (hipGetLastError() != hipSuccess) return fail("key kernel");
+    size_t tmpBytes = 0;
+    if (rocprim::radix_sort_pairs(nullptr, tmpBytes, keys.as<uint64_t>(), keysOut.as<uint64_t>(), idx.as<uint32_t>(), perm.as<uint32_t>(),
+                                  (size_t)nnz, 0, colBits + binBits, (hipStream_t) nullptr) != hipSuccess || sortTmp.alloc(tmpBytes))
+        return fail("sort workspace");
+    if (rocprim::radix_sort_pairs(sortTmp.p, tmpBytes, keys.as<uint64_t>(), keysOut.as<uint64_t>(), idx.as<uint32_t>(), perm.as<uint32_t>(),
+                                  (size_t)nnz, 0, colBits + binBits, (hipStream_t) nullptr) != hipSuccess)
+        return fail("sort");
+
+    bool wide = false;
+    if (const char* e = getenv("SPMV_SB_WIDE")) wide = atoi(e) != 0;                                   // tuning / tests only
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        if (fillFormat(f, wide, nnz, colBits, keysOut.as<uint64_t>(), perm.as<uint32_t>(), rowOf.as<uint32_t>(), d->AS,
+                       dBinStart.as<uint64_t>(), dOverflow.as<uint32_t>()))
+            return fail("scatter");
+        uint32_t ovf = 0;
+        if (hipMemcpy(&ovf, dOverflow.p, 4, hipMemcpyDeviceToHost) != hipSuccess) return fail("overflow flag");
+        if (!ovf || wide) break;
+        wide = true;                                  // some step spans >= 2^17 columns: 32-bit columns + 16-bit rows
+    }
+    static bool attrSet = false;
+    if (!attrSet) {
+        if (hipFuncSetAttribute((const void*)sb_spmv_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, SB_R_MAX * 8 + sizeof(SbLds)) ||
+            hipFuncSetAttribute((const void*)sb_spmv_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, SB_R_MAX * 8 + sizeof(SbLds)))
+            return fail("kernel attribute");
+        attrSet = true;
+    }
+    const uint64_t cells = steps * SB_STEP;
+    f->bytes = cells * (f->wide ? 14 : 12) + (f->wide ? 0 : steps * 4) + ((size_t)B + 1) * 8;
+    if (hipEventRecord(ev1, nullptr) != hipSuccess || hipEventSynchronize(ev1) != hipSuccess) return fail("synchronise");
+    float ms = 0;
+    (void)hipEventElapsedTime(&ms, ev0, ev1);
+    f->buildMs = ms;
+    d->stripes = f;
+    return EXIT_SUCCESS;
+}
+
+int enqueueStripes(DevMat* d, const double* x, double* y, hipStream_t stream) {
+    StripeFormat* f = d->stripes;
+    if (!f) return EXIT_FAILURE;
+    static int cus = 0;                              // one workgroup per CU (its bin of y fills the LDS): the persistent grid
+    if (!cus) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return EXIT_FAILURE;
+        cus = std::max(1, prop.multiProcessorCount);
+    }
+    // tuning knobs (environment, read once): SPMV_SB_SYNC=0 switches the leader throttle off, SPMV_SB_WINDOW is its
+    // width in entries
+    static int syncOn = -1;
+    static uint32_t windowEntries = 8192;
+    if (syncOn < 0) {
+        syncOn = 1;
+        if (const char* e = getenv("SPMV_SB_SYNC")) syncOn = atoi(e) != 0;
+        if (const char* e = getenv("SPMV_SB_WINDOW")) { const long v = atol(e); if (v >= 128 && v <= (1l << 30)) windowEntries = (uint32_t)v; }
+    }
+    const uint32_t grid = std::min<uint32_t>(f->B, (uint32_t)cus);
+    const bool sync = syncOn && grid > 1;
+    const uint32_t window = std::max<uint32_t>(1, windowEntries / (SB_DEPTH * SB_STEP));
+    SbSync* st = sync ? static_cast<SbSync*>(f->sync) : nullptr;
+    if (st && hipMemsetAsync(st, 0, sizeof(SbSync), stream) != hipSuccess) return EXIT_FAILURE;
+    const size_t lds = (size_t)8 * f->R + sizeof(SbLds);
+    if (f->wide)
+        hipLaunchKernelGGL(sb_spmv_kernel<true>, dim3(grid), dim3(SB_THREADS), lds, stream, f->B, f->binRow, f->binStep, f->val, f->cr,
+                           f->lrowW, f->stepBase, x, y, f->R, st, window, f->ticketsPerBin);
+    else
+        hipLaunchKernelGGL(sb_spmv_kernel<false>, dim3(grid), dim3(SB_THREADS), lds, stream, f->B, f->binRow, f->binStep, f->val, f->cr,
+                           f->lrowW, f->stepBase, x, y, f->R, st, window, f->ticketsPerBin);
+    return hipGetLastError() == hipSuccess ? EXIT_SUCCESS : EXIT_FAILURE;
+}
+
+}  // namespace spmvhip
+
+#ifdef SPMV_SB_DEBUG
+extern "C" int spmvHipStripesDebugDump(uint64_t* host, size_t words) {
+    return hipMemcpyFromSymbol(host, HIP_SYMBOL(spmvhip::sb_dbg), std::min<size_t>(words, 8 * 8192) * 8) == hipSuccess ? 0 : 1;
+}
+#endif

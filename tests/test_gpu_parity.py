@@ -65,6 +65,16 @@ def _cases():
     lw[123] = 30000
     lw[39999] = 5000
     cases["wide"] = (Mw, Nw) + random_csr(rng, Mw, Nw, lw)
+    # very wide and nearly empty: 128 column-sorted entries of a row bin span more than 2^17 columns (the stripes
+    # kernel's 32-bit-column encoding); column ids up to 4 M
+    Mh, Nh = 3000, 4_000_000
+    lh = rng.integers(0, 4, size=Mh)
+    IRPh = np.zeros(Mh + 1, dtype=np.uint64)
+    IRPh[1:] = np.cumsum(lh)
+    JAh = np.empty(int(IRPh[-1]), dtype=np.uint64)
+    for r in range(Mh):
+        JAh[int(IRPh[r]):int(IRPh[r + 1])] = np.sort(rng.choice(Nh, size=int(lh[r]), replace=False))
+    cases["hyper-sparse"] = (Mh, Nh, IRPh, JAh, rng.uniform(-1, 1, size=JAh.size))
     return cases
 
 
@@ -91,7 +101,7 @@ def _run(api, launcher, dmat, x, rows):
     ("hipSpMVRowsCSR", 0, True), ("hipSpMVRowsCSR", 1, True), ("hipSpMVRowsCSR", 2, True), ("hipSpMVRowsCSR", 3, True),
     ("hipSpMVWarpPerRowCSR", 0, False), ("hipSpMVWarpPerRowCSR", 1, False), ("hipSpMVWarpPerRowCSR", 2, False),
     ("hipSpMVWarpPerRowCSR", 3, False),
-    ("hipSpMVTilesCSR", -1, False), ("hipSpMVRowsSELL", -1, False)])
+    ("hipSpMVTilesCSR", -1, False), ("hipSpMVStripesCSR", -1, False), ("hipSpMVRowsSELL", -1, False)])
 def test_csr(api, oracle, name, launcher, variant, exact):
     M, N, IRP, JA, AS = CASES[name]
     x = _x(np.random.default_rng(7), N)
@@ -104,8 +114,13 @@ def test_csr(api, oracle, name, launcher, variant, exact):
     if launcher == "hipSpMVRowsSELL":                   # one lane per row, ascending j: exact for rows <= 256 entries
         short = np.diff(IRP.astype(np.int64)) <= 256
         assert np.array_equal(y[short], y_ref[short])
-    if launcher == "hipSpMVTilesCSR" and JA.size:       # second call re-uses the built format
+    if launcher in ("hipSpMVTilesCSR", "hipSpMVStripesCSR") and JA.size:       # second call re-uses the built format
         assert np.max(np.abs(_run(api, launcher, dmat, x, M) - y)) <= 1e-15    # arrival-order sums differ in the last bits
+    if launcher == "hipSpMVStripesCSR" and JA.size:
+        import ctypes as C
+        wide = C.c_int(-1)
+        assert api.lib.spmvHipStripesShape(C.byref(dmat.handle), None, None, C.byref(wide), None) == 0
+        assert wide.value == (1 if name == "hyper-sparse" else 0)
     dmat.free()
     assert not np.isnan(y).any(), "rows left unwritten (poison survived)"
     assert np.max(np.abs(y - y_ref), initial=0.0) <= GATE
@@ -172,7 +187,8 @@ def test_synth_device_matches_twin_and_oracle(api, oracle):
             assert (d[mask] > 0).all() and ja_ref.max() < w.N
             x = synth.make_x(w.N, w.cfg)
             y_ref = oracle.csr_serial_dev(irp.astype(np.uint32), ja_ref, as_ref, x)
-            for launcher, exact in (("hipSpMVRowsCSR", True), ("hipSpMVWarpPerRowCSR", False), ("hipSpMVTilesCSR", False), ("hipSpMVRowsSELL", False)):
+            for launcher, exact in (("hipSpMVRowsCSR", True), ("hipSpMVWarpPerRowCSR", False), ("hipSpMVTilesCSR", False),
+                                        ("hipSpMVStripesCSR", False), ("hipSpMVRowsSELL", False)):
                 y = _run(api, launcher, dm, x, w.N)
                 assert np.max(np.abs(y - y_ref)) <= GATE
                 if exact:
@@ -215,7 +231,7 @@ def test_full_size_spot_checks(api, oracle, key):
         assert np.array_equal(ja_dev, ja)
         refs.append(oracle.csr_serial_dev((irp[r0:r1 + 1] - irp[r0]).astype(np.uint32), ja, as_, x))
     for launcher, exact in (("hipSpMVWarpPerRowCSR", False), ("hipSpMVRowsCSR", True), ("hipSpMVTilesCSR", False),
-                            ("hipSpMVRowsSELL", False)):
+                            ("hipSpMVStripesCSR", False), ("hipSpMVRowsSELL", False)):
         dy.poison()
         api.spmv(launcher, dm, dx, dy)
         y = dy.down()
@@ -228,7 +244,7 @@ def test_full_size_spot_checks(api, oracle, key):
         dx2 = api.DeviceVector(w.N).up(2.0 * x)
         dy.poison()
         api.spmv(launcher, dm, dx2, dy)
-        if launcher == "hipSpMVTilesCSR":       # arrival-order sums: linear up to rounding only
+        if launcher in ("hipSpMVTilesCSR", "hipSpMVStripesCSR"):       # arrival-order sums: linear up to rounding only
             assert np.max(np.abs(dy.down() - 2.0 * y)) <= 1e-15
         else:
             assert np.array_equal(dy.down(), 2.0 * y)
@@ -271,7 +287,8 @@ def test_64bit_row_pointers_small(api, oracle):
     assert api.lib.spmvHipAdoptCSR(C.byref(dm.handle), M, N, JA.size, d_irp.ptr, 8, d_ja.ptr, d_as.ptr, None) == 0
     dm.keep = [d_irp, d_ja, d_as]
     for launcher, variants, exact in (("hipSpMVRowsCSR", (0, 1, 2, 3), True), ("hipSpMVWarpPerRowCSR", (0, 1, 2, 3), False),
-                                      ("hipSpMVTilesCSR", (-1,), False), ("hipSpMVRowsSELL", (-1,), False)):
+                                      ("hipSpMVTilesCSR", (-1,), False), ("hipSpMVStripesCSR", (-1,), False),
+                                      ("hipSpMVRowsSELL", (-1,), False)):
         for v in variants:
             if v >= 0:
                 api.set_variant(launcher, v)
@@ -312,8 +329,9 @@ def test_more_than_4g_nnz(api, oracle):
             assert np.max(np.abs(y[r0:r1] - yr)) <= GATE
             if exact:
                 assert np.array_equal(y[r0:r1], yr)
-    with pytest.raises(api.SpmvHipError):
-        api.spmv("hipSpMVTilesCSR", dm, dx, dy)
+    for launcher in ("hipSpMVTilesCSR", "hipSpMVStripesCSR"):
+        with pytest.raises(api.SpmvHipError):
+            api.spmv(launcher, dm, dx, dy)
     dm.free()
 
 
@@ -397,7 +415,7 @@ def test_degenerate_shapes_all_launchers(api, oracle):
         x = np.linspace(1e-5, 3e-5, N)
         y_ref = oracle.csr_serial(IRP, JA, AS, x)
         dm = api.spMatCpyCSR(api.HostCSR(M, N, IRP, JA, AS))
-        for launcher in ("hipSpMVRowsCSR", "hipSpMVWarpPerRowCSR", "hipSpMVTilesCSR", "hipSpMVRowsSELL"):
+        for launcher in ("hipSpMVRowsCSR", "hipSpMVWarpPerRowCSR", "hipSpMVTilesCSR", "hipSpMVStripesCSR", "hipSpMVRowsSELL"):
             y = _run(api, launcher, dm, x, M)
             assert not np.isnan(y).any(), (name, launcher)
             assert np.max(np.abs(y - y_ref), initial=0.0) <= 1e-18, (name, launcher)
