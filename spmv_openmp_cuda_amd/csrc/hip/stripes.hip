@@ -229,8 +229,13 @@ __device__ __forceinline__ void sb_add(double* yb, const SbStream& s, const SbGa
 // is not waited for) and mark their slot done when they leave, and a wait that exceeds its spin budget switches
 // the throttle off for that workgroup: the protocol changes speed, never results, and cannot hang.
 // State is zeroed by a memset node in front of every launch.
-struct SbSync { uint32_t count[8]; uint32_t pad[8]; uint32_t prog[8 * 64]; };
+struct SbSync { uint32_t line[8][64]; };            // per XCD: words 0..62 progress slots, word 63 the number of registered workgroups
 constexpr uint32_t SB_SYNC_OFF = 0xFFFFFFFFu;
+constexpr uint32_t SB_SYNC_SLOTS = 63;
+#ifndef SPMV_SB_BEAT
+#define SPMV_SB_BEAT 8
+#endif
+constexpr uint32_t SB_SYNC_BEAT = SPMV_SB_BEAT;
 constexpr uint32_t SB_SPIN_BUDGET = 1u << 14;       // sleeps of ~0.4 us: a few ms in total, then the workgroup stops throttling
 
 struct SbLds { uint32_t ctr, lim, slot, budget; };   // behind the bin's y in LDS
@@ -241,43 +246,65 @@ __device__ __forceinline__ uint32_t sb_wave_min(uint32_t v) {
     return v;
 }
 
-// next ticket of the workgroup (one LDS atomic by lane 0, broadcast); publishes the progress and waits while the
-// ticket is more than `window` ahead of the XCD's slowest workgroup
-__device__ __forceinline__ uint32_t sb_ticket(SbLds* l, uint32_t lane, SbSync* sync, uint32_t p0, uint32_t window) {
+// Progress words are written with PLAIN stores and read with sc1 loads: writers and readers of a line sit on one XCD
+// (slots are handed out per XCC id), whose L2 is their point of coherence -- a plain store is written through the
+// L1 and stays in that L2, an sc1 load bypasses the L1 and is served by it.  (sc1 / atomic stores DROP the line from
+// the L2: every reader then waited for the fabric, 5 ms instead of 0.9 on c3.)
+// (A volatile store compiles to `flat_store sc0 sc1` + `s_waitcnt vmcnt(0)` -- a full drain per publish; a relaxed
+// workgroup-scope atomic store is the plain `global_store_dword` that is wanted and cannot be optimised away.)
+__device__ __forceinline__ void sb_publish(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+
+// the XCD's progress line as loaded by 64 lanes -> slowest registered workgroup's progress + window
+__device__ __forceinline__ uint32_t sb_limit(uint32_t v, uint32_t lane, uint32_t window) {
+    const uint32_t cnt = (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+    if (lane >= cnt || lane >= SB_SYNC_SLOTS) v = SB_SYNC_OFF;
+    const uint32_t m = sb_wave_min(v);
+    return m > SB_SYNC_OFF - window ? SB_SYNC_OFF : m + window;
+}
+
+// Next ticket of the workgroup (one LDS atomic by lane 0, broadcast).  With the throttle on: publishes the progress,
+// waits while the ticket is beyond the limit the workgroup last computed, and issues the load of the XCD's progress
+// line whose result the caller hands to sb_refresh() a little later (after its stream loads are issued: the limit
+// is refreshed once per ticket without any wavefront waiting for the round trip).
+__device__ __forceinline__ uint32_t sb_ticket(SbLds* l, uint32_t lane, SbSync* sync, uint32_t p0, uint32_t window, uint32_t& pend, bool& fresh) {
     uint32_t t = 0;
     if (lane == 0) t = atomicAdd(&l->ctr, 1u);
     t = (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
     const uint32_t slot = (uint32_t)__builtin_amdgcn_readfirstlane((int)l->slot);
+    pend = SB_SYNC_OFF;
+    fresh = false;
     if (slot != SB_SYNC_OFF) {                       // wavefront-uniform
-        const uint32_t P = p0 + t;
-        if (lane == 0) __hip_atomic_store(&sync->prog[slot], P, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const uint32_t P = p0 + t, xcc = slot / 64;
+        const bool beat = (t % SB_SYNC_BEAT) == 0;   // publish and refresh on every SB_SYNC_BEAT-th ticket only: the line is hot
+        if (beat && lane == 0) sb_publish(&sync->line[xcc][slot % 64], P);
         uint32_t lim = (uint32_t)__builtin_amdgcn_readfirstlane((int)l->lim);
-        if (P > lim) {
-            const uint32_t xcc = slot / 64;
-            uint32_t spins = 0;
-            for (;;) {
-                const uint32_t cnt = __hip_atomic_load(&sync->count[xcc], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                uint32_t v = __hip_atomic_load(&sync->prog[xcc * 64 + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (lane >= cnt) v = SB_SYNC_OFF;
-                const uint32_t m = sb_wave_min(v);
-                lim = m > SB_SYNC_OFF - window ? SB_SYNC_OFF : m + window;
-                if (lane == 0) l->lim = lim;
-                if (P <= lim) break;
-                if (++spins >= 64) {                 // long wait: charge the workgroup's budget, give up when it is spent
-                    spins = 0;
-                    uint32_t left = 0;
-                    if (lane == 0) left = atomicSub(&l->budget, 64u);
-                    left = (uint32_t)__builtin_amdgcn_readfirstlane((int)left);
-                    if (left <= 64u || left > SB_SPIN_BUDGET) {
-                        if (lane == 0) { l->slot = SB_SYNC_OFF; __hip_atomic_store(&sync->prog[slot], SB_SYNC_OFF, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-                        break;
-                    }
+        uint32_t spins = 0;
+        while (P > lim) {                            // too far ahead of the XCD's slowest workgroup: re-read, sleep
+            lim = sb_limit(__hip_atomic_load(&sync->line[xcc][lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), lane, window);
+            if (lane == 0) l->lim = lim;
+            if (P <= lim) break;
+            if (++spins >= 64) {                     // long wait: charge the workgroup's budget, give up when it is spent
+                spins = 0;
+                uint32_t left = 0;
+                if (lane == 0) left = atomicSub(&l->budget, 64u);
+                left = (uint32_t)__builtin_amdgcn_readfirstlane((int)left);
+                if (left <= 64u || left > SB_SPIN_BUDGET) {
+                    if (lane == 0) { l->slot = SB_SYNC_OFF; sb_publish(&sync->line[xcc][slot % 64], SB_SYNC_OFF); }
+                    return t;
                 }
-                __builtin_amdgcn_s_sleep(16);
             }
+            __builtin_amdgcn_s_sleep(16);
         }
+        if (beat) { pend = __hip_atomic_load(&sync->line[xcc][lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); fresh = true; }
     }
     return t;
+}
+
+__device__ __forceinline__ void sb_refresh(SbLds* l, uint32_t lane, SbSync* sync, uint32_t window, uint32_t pend, bool fresh) {
+    if (fresh) {                                     // wavefront-uniform
+        const uint32_t lim = sb_limit(pend, lane, window);
+        if (lane == 0 && l->slot != SB_SYNC_OFF) l->lim = lim;
+    }
 }
 
 #ifdef SPMV_SB_DEBUG          // tuning builds only: per-bin placement and progress stamps (100 MHz clock)
@@ -301,8 +328,8 @@ __global__ __launch_bounds__(SB_THREADS) void sb_spmv_kernel(
             uint32_t xcc;
             asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
             xcc &= 7u;
-            const uint32_t k = atomicAdd(&sync->count[xcc], 1u);
-            if (k < 64) slot = xcc * 64 + k;
+            const uint32_t k = atomicAdd(&sync->line[xcc][63], 1u);
+            if (k < SB_SYNC_SLOTS) slot = xcc * 64 + k;
         }
         l->slot = slot;
         l->lim = window;
@@ -333,6 +360,8 @@ __global__ __launch_bounds__(SB_THREADS) void sb_spmv_kernel(
         __syncthreads();
         if (s1 > s0) {
             sb_gather<WIDE>(g0, a, x);
+            uint32_t pend, tk;
+            bool fresh;
 #ifdef SPMV_SB_DEBUG
             const uint32_t quarter = (s1 - s0) / 4;
             uint32_t nextMark = 1;
@@ -342,11 +371,13 @@ __global__ __launch_bounds__(SB_THREADS) void sb_spmv_kernel(
 #define SB_PROGRESS(S) do { } while (0)
 #endif
             // one stage: CUR is added, NXT gathered, FAR (the set CUR's predecessor freed) streamed with a fresh ticket
-#define SB_STAGE(CUR, NXT, FAR, GC, GN)                                                                          \
-            if (CUR.first >= s1) break;                                                                          \
-            sb_gather<WIDE>(GN, NXT, x);                                                                         \
-            sb_stream<WIDE>(FAR, sb_ticket(l, lane, sync, p0, window), s0, s1, lane, val, cr, lrowW, stepBase); \
-            sb_add<WIDE>(yb, CUR, GC, s1);                                                                       \
+#define SB_STAGE(CUR, NXT, FAR, GC, GN)                                                                                \
+            if (CUR.first >= s1) break;                                                                                \
+            tk = sb_ticket(l, lane, sync, p0, window, pend, fresh);      /* the progress-line load is the OLDEST of the stage */ \
+            sb_gather<WIDE>(GN, NXT, x);                                                                               \
+            sb_stream<WIDE>(FAR, tk, s0, s1, lane, val, cr, lrowW, stepBase);                                          \
+            sb_refresh(l, lane, sync, window, pend, fresh);                                                             \
+            sb_add<WIDE>(yb, CUR, GC, s1);                                                                             \
             SB_PROGRESS(CUR);
             for (;;) {
                 SB_STAGE(a, b, d, g0, g1)
@@ -365,7 +396,7 @@ __global__ __launch_bounds__(SB_THREADS) void sb_spmv_kernel(
         __syncthreads();                             // the next bin zeroes yb
     }
     if (threadIdx.x == 0 && l->slot != SB_SYNC_OFF)  // nobody waits for a workgroup that has left
-        __hip_atomic_store(&sync->prog[l->slot], SB_SYNC_OFF, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        sb_publish(&sync->line[l->slot / 64][l->slot % 64], SB_SYNC_OFF);
 }
 
 #define SB_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { fprintf(stderr, "libspmvhip: stripes: %s: %s\n", #expr, hipGetErrorString(e_)); return EXIT_FAILURE; } } while (0)
