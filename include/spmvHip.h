@@ -71,13 +71,18 @@ int spMatCpyCSR(spmat* host, spmat* dMat);
  * the reference kernels do: after transposition M holds the slot count and
  * MAX_ROW_NZ the row count, sparseUtils.c:168-171) -- pass `transposed` = 1 for
  * the latter.  Pitch = row length rounded up to 64 elements; pitchJA/pitchAS
- * are stored in elements as the reference does (cudaUtils.cu:81-83). */
+ * are stored in elements as the reference does (cudaUtils.cu:81-83).  The
+ * reference's field swap loses the column count of a transposed matrix; this
+ * repo's ellTranspose() keeps it in the (otherwise unused) host field pitchJA
+ * and the upload checks every column id against it (0 = unknown, unchecked). */
 int spMatCpyELL(spmat* host, spmat* dMat);
 int spMatCpyELLTransposed(spmat* hostT, spmat* dMat);
 /* Device-side CSR -> ELL of an uploaded matrix (slots = its longest row, row
  * lengths kept): transposed = 0 gives the row-major handle spMatCpyELL(ell)
- * would, 1 the column-major one of ellTranspose + spMatCpyELL.  The host-side
- * ELL size guard (parser.c:223-232) is not applied here. */
+ * would, 1 the column-major one of ellTranspose + spMatCpyELL.  ELL size
+ * guard: the reference's loader refuses an ELL copy above a fixed number of
+ * padded cells (parser.c:223-232); here the copy is refused (EXIT_FAILURE, no
+ * allocation attempted) when it does not fit the device memory that is free. */
 int spmvHipCsrToEll(spmat* dCsr, int transposed, spmat* dEll);
 /* Release the device arrays behind a handle (cudaUtils.h:70-78). */
 int hipFreeSpmat(spmat* dMat);
@@ -149,20 +154,14 @@ size_t spmvHipSellBytes(spmat* dMat);
 int spmvHipEnqueueCSR(spmat* dMat, int warpPerRow, double* dX, double* dY, void* stream);
 
 /* Kernel variants behind each launcher (for A/B measurement; default = best):
- *   hipSpMVRowsCSR        0 = one thread walks its row in global memory ("scalar")
- *                         1 = LDS-stream: coalesced span load, one thread sums its row
- *                             in ascending-j order (bit-identical to the serial oracle)
- *                         2 = (default) same, second generation: scalar-loaded block
- *                             table, row pointers staged in LDS, long rows first,
- *                             XCD-contiguous block order
- *                         3 = third generation: two row blocks per workgroup, the second
- *                             block's loads in flight under the first one's reduction
- *                             (measured 0-4 % slower than 2; kept for the A/B)
- *   hipSpMVWarpPerRowCSR  0 = one wavefront per row, __shfl_down tree
- *                         1 = adaptive: LDS segmented reduction for short rows,
- *                             wavefront-/workgroup-per-row for long ones
- *                         2 = (default) same, second generation
- *                         3 = third generation (two row blocks per workgroup), as above
+ *   hipSpMVRowsCSR        0 = one thread walks its row in global memory: the plain restatement of
+ *                             cudaSpMVRowsCSR (uncoalesced; 5-6x slower, profiles/r01_variants.md)
+ *                         1 = (default) LDS-stream kernel: coalesced span load, products parked in LDS, one
+ *                             thread sums its row in ascending-j order (bit-identical to the serial oracle)
+ *   hipSpMVWarpPerRowCSR  0 = one wavefront per row, __shfl_down tree (the reference kernel's intent, for
+ *                             every row)
+ *                         1 = (default) LDS-stream kernel with the LDS segmented reduction for short rows and
+ *                             wavefront-/workgroup-per-row sums for long ones
  * Returns EXIT_FAILURE for an unknown (launcher, variant). */
 int spmvHipSetVariant(const char* launcher, int variant);
 /* Use the RL array for ELL early exit (1, default when RL was uploaded) or walk
@@ -171,7 +170,11 @@ int spmvHipSetEllRowLens(int useRowLens);
 
 /* SPMV_INTERF-compatible wrappers (host vectors in/out, matrix uploaded and
  * cached on first use, keyed by the host spmat address) so the GPU path can sit
- * in SpmvCSRFuncs[]-style tables next to the OpenMP variants (SpMV.h:146-159). */
+ * in SpmvCSRFuncs[]-style tables next to the OpenMP variants (SpMV.h:146-159).
+ * The cache entry also remembers the shape and the IRP/JA/AS/RL pointers it was
+ * uploaded from and is re-uploaded when any of them differs; changing the values
+ * INSIDE the same arrays is not seen: call spmvHipDropCache() before a cached
+ * host matrix is modified or freed. */
 int spmvHipRowsCSR(spmat* mat, double* x, CONFIG* cfg, double* y);
 int spmvHipWarpPerRowCSR(spmat* mat, double* x, CONFIG* cfg, double* y);
 int spmvHipRowsELL(spmat* mat, double* x, CONFIG* cfg, double* y);
@@ -235,16 +238,29 @@ int spmvHipPeerPushJoin(void);
  * all-gather fused into the kernel as direct xGMI stores).  Enqueue-only when
  * spmvHipSetSync(0).  spmvHipTilesShape builds the format if needed. */
 int spmvHipTilesShape(spmat* dMat, unsigned* nBins, unsigned* rowsPerBin);
-/* Rows per bin of the formats built AFTER this call (0 = automatic, else 64..20000).  Phase 2 finishes its bins in
- * rounds of one workgroup per CU, and rows can only leave for the other ranks when their bin is finished: when the
- * exchange is the longer part of a step, smaller bins (more rounds) let it start earlier, at the price of shorter
- * tiles (N = 8 shard of c5: 1.19 ms automatic, 1.26 ms with half-size bins, 1.43 ms with quarter-size ones). */
-int spmvHipSetTilesRowsPerBin(unsigned rows);
-/* Tapered bins for the formats built AFTER this call: one round (256) of quarter-height bins first and last, full-
- * height bins between -- the first round sets when rows start to travel, the last what is still to be sent when
- * phase 2 ends, the bins between keep the tile length.  rowsPerBin of spmvHipTilesShape is then the height of
- * the HIGHEST bin; spmvHipTilesBinRow gives the first row of any bin (bin == nBins: the row count). */
-int spmvHipSetTilesTaper(int on);
+/* Build options of the two-phase format (all zero / -1 = automatic).  They are arguments of the build, not
+ * process state: spmvHipBuildTilesOpt(dMat, &opts) builds -- or REbuilds -- the format of this handle with them.
+ *   rowsPerBin  0 or 64..20000.  Phase 2 finishes its bins in rounds of one workgroup per CU, and rows can only
+ *               leave for the other ranks when their bin is finished: when the exchange is the longer part of a
+ *               step, smaller bins (more rounds) let it start earlier, at the price of shorter tiles (N = 8 shard
+ *               of c5: 1.19 ms automatic, 1.26 ms with half-size bins, 1.43 ms with quarter-size ones).
+ *   taper       1: one round (one bin per CU) of quarter-height bins first and last, full-height bins between --
+ *               the first round sets when rows start to travel, the last what is still to be sent when phase 2
+ *               ends.  rowsPerBin of spmvHipTilesShape is then the height of the HIGHEST bin; spmvHipTilesBinRow
+ *               gives the first row of any bin (bin == nBins: the row count).
+ *   ntStore     1 / 0: phase 1 stores the products non-temporally / with the default policy; -1: by size
+ *               (products that fit the 256 MiB Infinity Cache are kept there).
+ *   chunk       entries per phase-1 work item, 0 or 4096..2^24. */
+typedef struct { unsigned rowsPerBin; int taper; int ntStore; unsigned chunk; } spmvTilesOpts;
+int spmvHipBuildTilesOpt(spmat* dMat, const spmvTilesOpts* opts);
+typedef struct {
+    unsigned nBins, rowsPerBin, nSlices;
+    int      taper, ntStore;
+    unsigned chunk;
+    double   buildMs;          /* device time of the one-time build */
+    size_t   bytes;            /* device memory of the format (the shared product workspace not included) */
+} spmvTilesInfo;
+int spmvHipTilesInfo(spmat* dMat, spmvTilesInfo* info);   /* zeros when the format has not been built */
 int spmvHipTilesBinRow(spmat* dMat, unsigned bin, ulong* firstRow);
 int hipSpMVTilesExpand(spmat* dMat, double* dX);
 int hipSpMVTilesReduce(spmat* dMat, unsigned binBegin, unsigned binEnd, double* dY, int nExtra, double* const* dExtra);

@@ -82,9 +82,25 @@ _sigs = {
     "hipSpMVTilesExpand": ([C.POINTER(spmat), _vp], _i),
     "hipSpMVTilesReduce": ([C.POINTER(spmat), C.c_uint, C.c_uint, _vp, _i, _vp], _i),
     "hipSpMVTilesReducePush": ([C.POINTER(spmat), _vp, _i, _vp], _i), "spmvHipTilesPushFailed": ([C.POINTER(spmat)], _i),
-    "spmvHipTilesPushJoin": ([], _i), "spmvHipSetTilesRowsPerBin": ([C.c_uint], _i),
-    "spmvHipSetTilesTaper": ([_i], _i), "spmvHipTilesBinRow": ([C.POINTER(spmat), C.c_uint, C.POINTER(C.c_ulong)], _i),
+    "spmvHipTilesPushJoin": ([], _i),
+    "spmvHipBuildTilesOpt": ([C.POINTER(spmat), _vp], _i), "spmvHipTilesInfo": ([C.POINTER(spmat), _vp], _i),
+    "spmvHipTilesBinRow": ([C.POINTER(spmat), C.c_uint, C.POINTER(C.c_ulong)], _i),
 }
+
+
+class spmvTilesOpts(C.Structure):
+    """include/spmvHip.h `spmvTilesOpts` (0 / 0 / -1 / 0 = automatic)."""
+    _fields_ = [("rowsPerBin", C.c_uint), ("taper", _i), ("ntStore", _i), ("chunk", C.c_uint)]
+
+    def __init__(self, rowsPerBin=0, taper=0, ntStore=-1, chunk=0):
+        super().__init__(rowsPerBin, taper, ntStore, chunk)
+
+
+class spmvTilesInfo(C.Structure):
+    _fields_ = [("nBins", C.c_uint), ("rowsPerBin", C.c_uint), ("nSlices", C.c_uint), ("taper", _i), ("ntStore", _i),
+                ("chunk", C.c_uint), ("buildMs", C.c_double), ("bytes", _sz)]
+
+
 IPC_HANDLE_BYTES = 64
 MAX_PEERS = 15
 for _name, (_args, _res) in _sigs.items():
@@ -206,6 +222,7 @@ class HostELL:
         if transposed:
             s.M, s.N, s.MAX_ROW_NZ = K, M, M
             s.dev = SPMAT_TAG_ELL_TRANSPOSED
+            s.pitchJA = N                       # column count for the upload's range check (see ellTranspose)
         else:
             s.M, s.N, s.MAX_ROW_NZ = M, N, K
         s.JA = self.JA.ctypes.data_as(C.POINTER(C.c_ulong))
@@ -337,6 +354,18 @@ def spmv(launcher: str, dmat: DeviceMatrix, dx: DeviceVector, dy: DeviceVector, 
     """Run one of the five HIP launchers; raises on EXIT_FAILURE."""
     fn = SPMV_LAUNCHERS[launcher]
     _check(fn(C.byref(dmat.handle), dx.ptr, cfg if cfg is not None else CONFIG(), dy.ptr), launcher)
+
+
+def build_tiles(dmat: DeviceMatrix, rowsPerBin=0, taper=False, ntStore=-1, chunk=0):
+    """spmvHipBuildTilesOpt: (re)build the two-phase format of this handle with explicit options."""
+    o = spmvTilesOpts(int(rowsPerBin), 1 if taper else 0, int(ntStore), int(chunk))
+    _check(lib.spmvHipBuildTilesOpt(C.byref(dmat.handle), C.byref(o)), "spmvHipBuildTilesOpt")
+
+
+def tiles_info(dmat: DeviceMatrix) -> spmvTilesInfo:
+    info = spmvTilesInfo()
+    _check(lib.spmvHipTilesInfo(C.byref(dmat.handle), C.byref(info)), "spmvHipTilesInfo")
+    return info
 
 
 def set_variant(launcher: str, variant: int):

@@ -20,8 +20,8 @@ struct State {
     int         dev = 0;
     hipStream_t stream = nullptr;
     bool        sync = true;
-    int         variantRowsCSR = 2;     // 0 scalar, 1 LDS-stream SEQ (first generation), 2 second generation
-    int         variantWarpCSR = 2;     // 0 wavefront-per-row, 1 LDS-stream VEC (first generation), 2 second generation
+    int         variantRowsCSR = 1;     // 0 scalar restatement, 1 LDS-stream kernel (sequential row sums)
+    int         variantWarpCSR = 1;     // 0 wavefront-per-row restatement, 1 LDS-stream kernel (LDS segmented reduction)
     bool        ellRowLens = true;
     double      lastSeconds = 0;
     spmvDim3    lastGrid{0, 0, 0}, lastBlock{0, 0, 0};
@@ -46,28 +46,6 @@ DevMat* descOf(spmat* h, const char* who) {
     return d;
 }
 
-// Row blocks for csr_stream_kernel: consecutive rows are packed while their nnz
-// fit STREAM_NNZ (and at most STREAM_MAX_ROWS rows); a row longer than that is
-// a block of its own.
-template <typename I>
-void buildRowBlocks(const I* IRP, uint64_t M, std::vector<uint32_t>& blk, uint32_t& nLong, uint64_t& maxRow) {
-    blk.clear();
-    nLong = 0;
-    maxRow = 0;
-    blk.reserve(M / 64 + 2);
-    uint64_t r = 0;
-    blk.push_back(0);
-    while (r < M) {
-        const uint64_t start = IRP[r];
-        uint64_t e = r;
-        while (e < M && (uint64_t)IRP[e + 1] - start <= (uint64_t)STREAM_NNZ && e - r < STREAM_MAX_ROWS) ++e;
-        if (e == r) { ++e; ++nLong; }       // single long row
-        r = e;
-        blk.push_back((uint32_t)r);
-    }
-    for (uint64_t i = 0; i < M; ++i) maxRow = std::max<uint64_t>(maxRow, (uint64_t)IRP[i + 1] - (uint64_t)IRP[i]);
-}
-
 // Block table of csr_stream2_kernel: rows packed while nnz <= STREAM_NNZ and rows <= STREAM2_MAX_ROWS;
 // a longer row is a block of its own, flagged, and all such blocks come first (longest first) so that
 // their serial tails overlap the rest of the grid.
@@ -76,6 +54,8 @@ int buildRowBlocks2(DevMat* d, const I* IRP, uint64_t M) {
     std::vector<uint4> info, longs;
     std::vector<uint64_t> base, longBase;
     info.reserve(M / 64 + 2); base.reserve(M / 64 + 2);
+    d->maxRowNnz = 0;
+    for (uint64_t i = 0; i < M; ++i) d->maxRowNnz = std::max<uint64_t>(d->maxRowNnz, (uint64_t)IRP[i + 1] - (uint64_t)IRP[i]);
     uint64_t r = 0;
     while (r < M) {
         const uint64_t start = IRP[r];
@@ -110,19 +90,12 @@ int buildRowBlocks2(DevMat* d, const I* IRP, uint64_t M) {
     return EXIT_SUCCESS;
 }
 
-int uploadRowBlocks(DevMat* d, const std::vector<uint32_t>& blk) {
-    d->nBlk = (uint32_t)blk.size() - 1;
-    HIP_TRY(hipMalloc(&d->blkRow, blk.size() * sizeof(uint32_t)));
-    HIP_TRY(hipMemcpy(d->blkRow, blk.data(), blk.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
-    return EXIT_SUCCESS;
-}
-
 void freeDesc(DevMat* d) {
     if (!d) return;
     if (d->owns) {
         (void)hipFree(d->IRP); (void)hipFree(d->JA); (void)hipFree(d->AS); (void)hipFree(d->RL);
     }
-    (void)hipFree(d->blkRow); (void)hipFree(d->blkInfo); (void)hipFree(d->blkBase);
+    (void)hipFree(d->blkInfo); (void)hipFree(d->blkBase);
     freeTiles(d->tiles);
     freeSell(d->sell);
     freeStripes(d->stripes);
@@ -212,34 +185,12 @@ __global__ __launch_bounds__(256) void csr_to_ell_kernel(uint32_t M, uint32_t K,
 }
 
 template <bool SEQ>
-static void launchStream(DevMat* d, double* x, double* y) {
-    if (d->irpBytes == 4)
-        hipLaunchKernelGGL((csr_stream_kernel<uint32_t, SEQ>), grid2d(d->nBlk, WG_THREADS), dim3(WG_THREADS), 0, S.stream,
-                           d->nBlk, d->blkRow, static_cast<const uint32_t*>(d->IRP), d->JA, d->AS, x, y);
-    else
-        hipLaunchKernelGGL((csr_stream_kernel<uint64_t, SEQ>), grid2d(d->nBlk, WG_THREADS), dim3(WG_THREADS), 0, S.stream,
-                           d->nBlk, d->blkRow, static_cast<const uint64_t*>(d->IRP), d->JA, d->AS, x, y);
-}
-
-
-template <bool SEQ>
 static void launchStream2(DevMat* d, double* x, double* y) {
     if (d->irpBytes == 4)
         hipLaunchKernelGGL((csr_stream2_kernel<uint32_t, SEQ>), grid2d(d->nBlk2, WG_THREADS), dim3(WG_THREADS), 0, S.stream,
                            d->nBlk2, d->nLong2, d->blkInfo, d->blkBase, static_cast<const uint32_t*>(d->IRP), d->JA, d->AS, x, y);
     else
         hipLaunchKernelGGL((csr_stream2_kernel<uint64_t, SEQ>), grid2d(d->nBlk2, WG_THREADS), dim3(WG_THREADS), 0, S.stream,
-                           d->nBlk2, d->nLong2, d->blkInfo, d->blkBase, static_cast<const uint64_t*>(d->IRP), d->JA, d->AS, x, y);
-}
-
-template <bool SEQ>
-static void launchStream3(DevMat* d, double* x, double* y) {
-    const uint64_t wgs = (uint64_t)d->nLong2 + ((uint64_t)(d->nBlk2 - d->nLong2) + 1) / 2;
-    if (d->irpBytes == 4)
-        hipLaunchKernelGGL((csr_stream3_kernel<uint32_t, SEQ>), grid2d(wgs, WG_THREADS), dim3(WG_THREADS), 0, S.stream,
-                           d->nBlk2, d->nLong2, d->blkInfo, d->blkBase, static_cast<const uint32_t*>(d->IRP), d->JA, d->AS, x, y);
-    else
-        hipLaunchKernelGGL((csr_stream3_kernel<uint64_t, SEQ>), grid2d(wgs, WG_THREADS), dim3(WG_THREADS), 0, S.stream,
                            d->nBlk2, d->nLong2, d->blkInfo, d->blkBase, static_cast<const uint64_t*>(d->IRP), d->JA, d->AS, x, y);
 }
 
@@ -251,6 +202,18 @@ static void launchEllGroup(DevMat* d, bool rl, dim3 grid, dim3 block, double* x,
 
 
 }  // namespace
+
+// row pointers must start at 0, never decrease and end at NZ: the kernels trust them for every AS/JA access
+template <typename I>
+static bool rowPointersOk(const I* IRP, uint64_t M, uint64_t NZ, const char* who) {
+    if ((uint64_t)IRP[0] != 0 || (uint64_t)IRP[M] != NZ) {
+        ERR("%s: inconsistent row pointers (IRP[0]=%lu IRP[M]=%lu NZ=%lu)", who, (unsigned long)IRP[0], (unsigned long)IRP[M], (unsigned long)NZ);
+        return false;
+    }
+    for (uint64_t r = 0; r < M; ++r)
+        if (IRP[r] > IRP[r + 1]) { ERR("%s: row pointers decrease at row %lu (%lu > %lu)", who, (unsigned long)r, (unsigned long)IRP[r], (unsigned long)IRP[r + 1]); return false; }
+    return true;
+}
 
 // Upload an (nRows x nCols) row-major host array pair with a padded pitch.
 static int uploadPitched(DevMat* d, const ulong* hJA, const double* hAS, size_t nRows, size_t nCols,
@@ -279,13 +242,15 @@ static int ellUpload(spmat* m, spmat* dst, bool transposed) {
     // reference field convention: a transposed matrix keeps slots in M and rows in MAX_ROW_NZ / N
     const ulong rows  = transposed ? m->MAX_ROW_NZ : m->M;
     const ulong slots = transposed ? m->M : m->MAX_ROW_NZ;
-    const ulong cols  = transposed ? 0 : m->N;      // column count is not recoverable from a transposed struct
+    // a transposed struct has lost the column count to the reference's field swap; this repo's ellTranspose (and
+    // api.HostELL.transpose) keep it in the unused host field pitchJA -- 0 = unknown, column ids then cannot be checked
+    const ulong cols  = transposed ? (ulong)m->pitchJA : m->N;
     if (rows >= (1ull << 32) - 1 || slots >= (1ull << 32) - 1) { ERR("spMatCpyELL: dimensions exceed 32-bit ids"); return EXIT_FAILURE; }
     DevMat* d = new DevMat;
     d->kind = transposed ? Kind::ELL_COLMAJOR : Kind::ELL_ROWMAJOR;
     d->M = rows; d->N = cols; d->NZ = m->NZ; d->K = slots;
     int rc;
-    const ulong colLimit = transposed ? 0xFFFFFFFFul : (m->N ? m->N - 1 : 0);
+    const ulong colLimit = transposed ? (cols ? cols - 1 : 0xFFFFFFFFul) : (m->N ? m->N - 1 : 0);
     if (transposed) rc = uploadPitched(d, m->JA, m->AS, slots, rows, (rows + 63) / 64 * 64, colLimit);
     else            rc = uploadPitched(d, m->JA, m->AS, rows, slots, (slots + 15) / 16 * 16, colLimit);
     if (!rc && m->RL) rc = narrowUpload<uint32_t>(&d->RL, m->RL, rows, slots, "RL");
@@ -295,20 +260,32 @@ static int ellUpload(spmat* m, spmat* dst, bool transposed) {
 }
 
 namespace {
-struct Cached { spmat handle; double* dx = nullptr; double* dy = nullptr; int kind = 0; };
+// Device copy of a host matrix behind the SPMV_INTERF-style wrappers.  The key is the host struct's address; the
+// entry also remembers the shape and the array pointers it was uploaded from, and is re-uploaded when any of them
+// differs (a freed struct whose address malloc handed out again, a matrix re-loaded in place).  Changing the VALUES
+// inside the same arrays is invisible here: call spmvHipDropCache() before a cached host matrix is modified or freed.
+struct Cached {
+    spmat handle{}; double* dx = nullptr; double* dy = nullptr; int kind = 0;
+    ulong M = 0, N = 0, NZ = 0, K = 0; const void *irp = nullptr, *ja = nullptr, *as = nullptr, *rl = nullptr;
+    bool sameSource(const spmat* m, int k) const {
+        return kind == k && M == m->M && N == m->N && NZ == m->NZ && K == m->MAX_ROW_NZ && irp == m->IRP && ja == m->JA && as == m->AS && rl == m->RL;
+    }
+    void release() { hipFreeSpmat(&handle); (void)hipFree(dx); (void)hipFree(dy); dx = dy = nullptr; }
+};
 std::map<const spmat*, Cached> g_cache;
 
 int hostCall(spmat* mat, double* x, CONFIG* cfg, double* y, int kind, SPMV_HIP_INTERF fn) {
-    if (!ready("spmvHip*")) return EXIT_FAILURE;
+    if (!ready("spmvHip*") || !mat || !x || !y) return EXIT_FAILURE;
     auto it = g_cache.find(mat);
-    if (it == g_cache.end() || it->second.kind != kind) {
-        if (it != g_cache.end()) { hipFreeSpmat(&it->second.handle); (void)hipFree(it->second.dx); (void)hipFree(it->second.dy); g_cache.erase(it); }
+    if (it != g_cache.end() && !it->second.sameSource(mat, kind)) { it->second.release(); g_cache.erase(it); it = g_cache.end(); }
+    if (it == g_cache.end()) {
         Cached c; c.kind = kind;
+        c.M = mat->M; c.N = mat->N; c.NZ = mat->NZ; c.K = mat->MAX_ROW_NZ; c.irp = mat->IRP; c.ja = mat->JA; c.as = mat->AS; c.rl = mat->RL;
         int rc;
-        ulong rows = mat->M, cols = mat->N;
         if (kind == 0) rc = spMatCpyCSR(mat, &c.handle);
         else if (kind == 1) rc = spMatCpyELL(mat, &c.handle);
         else {  // column-major ELL: transposition is done on the fly from the row-major host matrix
+            if (!mat->JA || !mat->AS) { ERR("spmvHipRowsELL: host matrix has no ELL arrays"); return EXIT_FAILURE; }
             spmat t = *mat;
             std::vector<ulong> ja(mat->M * mat->MAX_ROW_NZ);
             std::vector<double> as(mat->M * mat->MAX_ROW_NZ);
@@ -319,10 +296,11 @@ int hostCall(spmat* mat, double* x, CONFIG* cfg, double* y, int kind, SPMV_HIP_I
                 }
             t.JA = ja.data(); t.AS = as.data();
             t.M = mat->MAX_ROW_NZ; t.N = mat->M; t.MAX_ROW_NZ = mat->M;
+            t.pitchJA = mat->N;                      // column count for the upload's range check
             rc = spMatCpyELLTransposed(&t, &c.handle);
         }
         if (rc) return EXIT_FAILURE;
-        if (spmvHipVecAlloc(&c.dx, cols) || spmvHipVecAlloc(&c.dy, rows)) return EXIT_FAILURE;
+        if (spmvHipVecAlloc(&c.dx, mat->N) || spmvHipVecAlloc(&c.dy, mat->M)) { c.release(); return EXIT_FAILURE; }
         it = g_cache.emplace(mat, c).first;
     }
     Cached& c = it->second;
@@ -390,8 +368,8 @@ int spmvHipDeviceSynchronize(void) { HIP_TRY(hipDeviceSynchronize()); return EXI
 
 int spmvHipSetVariant(const char* launcher, int variant) {
     if (!launcher) return EXIT_FAILURE;
-    if (!strcmp(launcher, "hipSpMVRowsCSR") && variant >= 0 && variant <= 3) { S.variantRowsCSR = variant; return EXIT_SUCCESS; }
-    if (!strcmp(launcher, "hipSpMVWarpPerRowCSR") && variant >= 0 && variant <= 3) { S.variantWarpCSR = variant; return EXIT_SUCCESS; }
+    if (!strcmp(launcher, "hipSpMVRowsCSR") && variant >= 0 && variant <= 1) { S.variantRowsCSR = variant; return EXIT_SUCCESS; }
+    if (!strcmp(launcher, "hipSpMVWarpPerRowCSR") && variant >= 0 && variant <= 1) { S.variantWarpCSR = variant; return EXIT_SUCCESS; }
     ERR("spmvHipSetVariant: unknown (%s, %d)", launcher, variant);
     return EXIT_FAILURE;
 }
@@ -445,7 +423,7 @@ int spMatCpyCSR(spmat* m, spmat* dst) {
     if (!ready("spMatCpyCSR") || !m || !dst) return EXIT_FAILURE;
     if (!m->IRP || (m->NZ && (!m->JA || !m->AS))) { ERR("spMatCpyCSR: host matrix has no CSR arrays"); return EXIT_FAILURE; }
     if (m->M >= (1ull << 32) - 1 || m->N > (1ull << 32)) { ERR("spMatCpyCSR: %lu x %lu exceeds the 32-bit row/column ids of the device format", m->M, m->N); return EXIT_FAILURE; }
-    if (m->IRP[0] != 0 || m->IRP[m->M] != m->NZ) { ERR("spMatCpyCSR: inconsistent row pointers (IRP[0]=%lu IRP[M]=%lu NZ=%lu)", m->IRP[0], m->IRP[m->M], m->NZ); return EXIT_FAILURE; }
+    if (!rowPointersOk(m->IRP, m->M, m->NZ, "spMatCpyCSR")) return EXIT_FAILURE;
     DevMat* d = new DevMat;
     d->kind = Kind::CSR;
     d->M = m->M; d->N = m->N; d->NZ = m->NZ;
@@ -459,12 +437,7 @@ int spMatCpyCSR(spmat* m, spmat* dst) {
             !hipOk(hipMemcpy(d->AS, m->AS, m->NZ * sizeof(double), hipMemcpyHostToDevice), "hipMemcpy AS")) rc = EXIT_FAILURE;
     }
     if (!rc && m->RL) rc = narrowUpload<uint32_t>(&d->RL, m->RL, m->M, 0xFFFFFFFFul, "RL");
-    if (!rc) {
-        std::vector<uint32_t> blk;
-        buildRowBlocks(m->IRP, m->M, blk, d->nLongBlk, d->maxRowNnz);
-        rc = uploadRowBlocks(d, blk);
-        if (!rc) rc = buildRowBlocks2(d, m->IRP, m->M);
-    }
+    if (!rc) rc = buildRowBlocks2(d, m->IRP, m->M);
     if (rc) { freeDesc(d); return EXIT_FAILURE; }
     publish(dst, d, m->M, m->N, m->NZ, 0);
     return EXIT_SUCCESS;
@@ -482,15 +455,15 @@ int spmvHipAdoptCSR(spmat* dst, ulong M, ulong N, ulong NZ, const void* dIRP, in
         HIP_TRY(hipMemcpy(tmp.data(), dIRP, tmp.size(), hipMemcpyDeviceToHost));
         hIRP = tmp.data();
     }
+    if (irpBytes == 4 ? !rowPointersOk(static_cast<const uint32_t*>(hIRP), M, NZ, "spmvHipAdoptCSR")
+                      : !rowPointersOk(static_cast<const uint64_t*>(hIRP), M, NZ, "spmvHipAdoptCSR")) return EXIT_FAILURE;
     DevMat* d = new DevMat;
     d->kind = Kind::CSR; d->owns = false;
     d->M = M; d->N = N; d->NZ = NZ; d->irpBytes = irpBytes;
     d->IRP = const_cast<void*>(dIRP); d->JA = const_cast<uint32_t*>(dJA); d->AS = const_cast<double*>(dAS);
-    std::vector<uint32_t> blk;
-    int rc2;
-    if (irpBytes == 4) { buildRowBlocks(static_cast<const uint32_t*>(hIRP), M, blk, d->nLongBlk, d->maxRowNnz); rc2 = buildRowBlocks2(d, static_cast<const uint32_t*>(hIRP), M); }
-    else               { buildRowBlocks(static_cast<const uint64_t*>(hIRP), M, blk, d->nLongBlk, d->maxRowNnz); rc2 = buildRowBlocks2(d, static_cast<const uint64_t*>(hIRP), M); }
-    if (rc2 || uploadRowBlocks(d, blk)) { freeDesc(d); return EXIT_FAILURE; }
+    const int rc2 = irpBytes == 4 ? buildRowBlocks2(d, static_cast<const uint32_t*>(hIRP), M)
+                                  : buildRowBlocks2(d, static_cast<const uint64_t*>(hIRP), M);
+    if (rc2) { freeDesc(d); return EXIT_FAILURE; }
     publish(dst, d, M, N, NZ, 0);
     return EXIT_SUCCESS;
 }
@@ -508,6 +481,22 @@ int spmvHipCsrToEll(spmat* dCsr, int transposed, spmat* dEll) {
     d->M = rows; d->N = c->N; d->NZ = c->NZ; d->K = K;
     d->pitch = transposed ? (rows + 63) / 64 * 64 : (K + 15) / 16 * 16;
     const size_t cells = std::max<size_t>((transposed ? K : rows) * d->pitch, 1);
+    {   // ELL size guard.  The reference's loader refuses an ELL copy whose 2*M*maxRow padded cells exceed a fixed host
+        // budget (src/lib/parser.c:223-232, config.h:69-70: 6*2^27 cells); on the device the budget is what the GPU has
+        // free right now -- the unclipped power-law matrix (10 M rows x 50 k slots = 6 TB) is refused here, before any
+        // allocation, the same matrix clipped to 64 slots (7.7 GB) passes.
+        size_t freeB = 0, totalB = 0;
+        const unsigned __int128 need128 = (unsigned __int128)(transposed ? K : rows) * d->pitch * 12 + (unsigned __int128)rows * 4;
+        const size_t need = need128 > (unsigned __int128)~(size_t)0 ? ~(size_t)0 : (size_t)need128;
+        if (hipMemGetInfo(&freeB, &totalB) != hipSuccess) freeB = totalB = 0;
+        if (need > freeB) {
+            ERR("spmvHipCsrToEll: ELL copy of %lu rows x %lu slots needs %.1f GB, device has %.1f GB free: refused "
+                "(the reference refuses above 6*2^27 padded cells, parser.c:223-232)", (unsigned long)rows, (unsigned long)K,
+                (double)need * 1e-9, (double)freeB * 1e-9);
+            delete d;
+            return EXIT_FAILURE;
+        }
+    }
     if (!hipOk(hipMalloc(&d->JA, cells * sizeof(uint32_t)), "hipMalloc ELL JA") ||
         !hipOk(hipMalloc(&d->AS, cells * sizeof(double)), "hipMalloc ELL AS") ||
         !hipOk(hipMalloc(&d->RL, std::max<size_t>(rows, 1) * sizeof(uint32_t)), "hipMalloc ELL RL") ||
@@ -562,13 +551,8 @@ int hipSpMVRowsCSR(spmat* dMat, double* dX, CONFIG cfg, double* dY) {
         else                  hipLaunchKernelGGL((csr_scalar_kernel<uint64_t>), grid, block, 0, S.stream, M, static_cast<const uint64_t*>(d->IRP), d->JA, d->AS, dX, dY);
         return L.finish("hipSpMVRowsCSR");
     }
-    if (S.variantRowsCSR == 1) {
-        Launch L(grid2d(d->nBlk, WG_THREADS), dim3(WG_THREADS));
-        launchStream<true>(d, dX, dY);
-        return L.finish("hipSpMVRowsCSR");
-    }
     Launch L(grid2d(d->nBlk2, WG_THREADS), dim3(WG_THREADS));
-    if (S.variantRowsCSR == 3) launchStream3<true>(d, dX, dY); else launchStream2<true>(d, dX, dY);
+    launchStream2<true>(d, dX, dY);
     return L.finish("hipSpMVRowsCSR");
 }
 
@@ -587,13 +571,8 @@ int hipSpMVWarpPerRowCSR(spmat* dMat, double* dX, CONFIG cfg, double* dY) {
         else                  hipLaunchKernelGGL((csr_vector_kernel<uint64_t>), grid, block, 0, S.stream, M, static_cast<const uint64_t*>(d->IRP), d->JA, d->AS, dX, dY);
         return L.finish("hipSpMVWarpPerRowCSR");
     }
-    if (S.variantWarpCSR == 1) {
-        Launch L(grid2d(d->nBlk, WG_THREADS), dim3(WG_THREADS));
-        launchStream<false>(d, dX, dY);
-        return L.finish("hipSpMVWarpPerRowCSR");
-    }
     Launch L(grid2d(d->nBlk2, WG_THREADS), dim3(WG_THREADS));
-    if (S.variantWarpCSR == 3) launchStream3<false>(d, dX, dY); else launchStream2<false>(d, dX, dY);
+    launchStream2<false>(d, dX, dY);
     return L.finish("hipSpMVWarpPerRowCSR");
 }
 
@@ -704,12 +683,19 @@ int spmvHipTilesShape(spmat* dMat, unsigned* nBins, unsigned* rowsPerBin) {
     return EXIT_SUCCESS;
 }
 
-int spmvHipSetTilesRowsPerBin(unsigned rows) {
-    if (setTilesRowsPerBin(rows)) { ERR("spmvHipSetTilesRowsPerBin: %u is not 0 (automatic) or 64..20000", rows); return EXIT_FAILURE; }
-    return EXIT_SUCCESS;
+int spmvHipBuildTilesOpt(spmat* dMat, const spmvTilesOpts* opts) {
+    DevMat* d = descOf(dMat, "spmvHipBuildTilesOpt");
+    if (!d) return EXIT_FAILURE;
+    if (d->kind != Kind::CSR || d->M == 0 || d->NZ == 0) { ERR("spmvHipBuildTilesOpt: needs a non-empty CSR handle"); return EXIT_FAILURE; }
+    return buildTiles(d, opts);
 }
 
-int spmvHipSetTilesTaper(int on) { return setTilesTaper(on); }
+int spmvHipTilesInfo(spmat* dMat, spmvTilesInfo* info) {
+    DevMat* d = descOf(dMat, "spmvHipTilesInfo");
+    if (!d || !info) return EXIT_FAILURE;
+    tilesInfo(d, info);
+    return EXIT_SUCCESS;
+}
 
 int spmvHipTilesBinRow(spmat* dMat, unsigned bin, ulong* firstRow) {
     DevMat* d = tilesReady(dMat, "spmvHipTilesBinRow");
@@ -849,7 +835,7 @@ int spmvHipWarpPerRowCSR(spmat* mat, double* x, CONFIG* cfg, double* y) { return
 int spmvHipRowsELL(spmat* mat, double* x, CONFIG* cfg, double* y) { return hostCall(mat, x, cfg, y, 2, &hipSpMVRowsELL); }
 int spmvHipWarpsPerRowELL(spmat* mat, double* x, CONFIG* cfg, double* y) { return hostCall(mat, x, cfg, y, 1, &hipSpMVWarpsPerRowELLNTrasposed); }
 int spmvHipDropCache(void) {
-    for (auto& kv : g_cache) { hipFreeSpmat(&kv.second.handle); (void)hipFree(kv.second.dx); (void)hipFree(kv.second.dy); }
+    for (auto& kv : g_cache) kv.second.release();
     g_cache.clear();
     return EXIT_SUCCESS;
 }

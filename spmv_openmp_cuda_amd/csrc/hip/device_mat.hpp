@@ -7,11 +7,13 @@
 //   RL   32-bit row lengths (optional)
 //   ELL  row-major  [rows ][pitch(slots)]  pitch = slots rounded up to 16 elements
 //        col-major  [slots][pitch(rows )]  pitch = rows  rounded up to 64 elements
-//   blkRow  row-block boundaries of the LDS-stream kernel (CSR only)
+//   blkInfo / blkBase  row blocks of the LDS-stream kernel (CSR only)
 #pragma once
 #include <hip/hip_runtime.h>
 #include <cstdint>
 #include <cstdio>
+
+#include "spmvHip.h"
 
 namespace spmvhip {
 
@@ -24,7 +26,6 @@ constexpr int      WAVE            = 64;
 #endif
 constexpr int      WG_THREADS      = SPMV_WG_THREADS;   // 4 wavefronts
 constexpr int      STREAM_NNZ      = SPMV_STREAM_NNZ;   // nnz staged in LDS per workgroup (16 KiB of fp64)
-constexpr uint32_t STREAM_MAX_ROWS = 2048;     // bounds a block made of empty / 1-nnz rows
 // 32-bit row pointers are used only below this nnz count, so that `j + stride`
 // in the kernels can never wrap around 2^32
 constexpr uint64_t IRP32_LIMIT     = (1ull << 32) - 65536;
@@ -47,12 +48,9 @@ struct DevMat {
     uint32_t* RL  = nullptr;
     size_t    pitch = 0;            // ELL pitch in elements (same for JA and AS)
     bool      owns = true;          // false for adopted arrays
-    // row blocks (CSR): block b covers rows [blkRow[b], blkRow[b+1])
-    uint32_t* blkRow = nullptr;
-    uint32_t  nBlk = 0;
-    uint32_t  nLongBlk = 0;         // blocks that are a single row longer than STREAM_NNZ
     uint64_t  maxRowNnz = 0;
-    // second-generation block table (csr_stream2_kernel): long rows first, then row order
+    // row blocks of the LDS-stream kernel (CSR): consecutive rows packed while their nnz <= STREAM_NNZ; a longer row is a
+    // block of its own; long rows first, then row order
     uint4*    blkInfo = nullptr;    // {first row, #rows, #nnz, long-row flag}
     uint64_t* blkBase = nullptr;    // nnz offset of the block
     uint32_t  nBlk2 = 0, nLong2 = 0;
@@ -72,7 +70,8 @@ int  enqueueStripes(DevMat* d, const double* x, double* y, hipStream_t stream);
 size_t stripesBytes(const DevMat* d);
 void stripesShape(const DevMat* d, uint32_t* bins, uint32_t* rowsPerBin, int* wide, double* buildMs);
 
-int  buildTiles(DevMat* d);                                     // tiles.hip
+int  buildTiles(DevMat* d, const spmvTilesOpts* opts = nullptr); // tiles.hip; explicit options replace an existing format
+void tilesInfo(const DevMat* d, spmvTilesInfo* out);
 void freeTiles(TileFormat* t);
 void freeTilesWorkspace();                                      // the per-device product workspace (8 B/nnz of the largest matrix)
 int  enqueueTiles(DevMat* d, const double* x, double* y, hipStream_t stream);
@@ -82,8 +81,6 @@ int  enqueueTilesReducePush(DevMat* d, double* y, int nExtra, double* const* ext
                             hipEvent_t evFork, hipEvent_t evJoin);
 int  tilesPushFailed(DevMat* d);
 void tilesShape(const DevMat* d, uint32_t* bins, uint32_t* rowsPerBin);
-int  setTilesRowsPerBin(uint32_t rows);
-int  setTilesTaper(int on);
 uint64_t tilesBinRow(const DevMat* d, uint32_t bin);
 hipStream_t libraryStream();                                    // abi.hip: the stream set with spmvHipSetStream
 size_t tilesBytes(const DevMat* d);

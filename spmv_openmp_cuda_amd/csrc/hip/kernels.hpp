@@ -3,7 +3,7 @@
 // What each kernel restates (reference paths relative to its root):
 //   csr_scalar_kernel      cudaSpMVRowsCSR                   src/SpMV_CUDA.cu:33-49
 //   csr_vector_kernel      cudaSpMVWarpPerRowCSR             src/SpMV_CUDA.cu:52-73   (as intended: every row)
-//   csr_stream_kernel      both of the above, MI355X-first: coalesced span load -> LDS -> per-row reduce
+//   csr_stream2_kernel     both of the above, MI355X-first: coalesced span load -> LDS -> per-row reduce
 //   ell_colmajor_thread    cudaSpMVRowsELL                   src/SpMV_CUDA.cu:79-96
 //   ell_rowmajor_thread    cudaSpMVRowsELLNNTransposed       src/SpMV_CUDA.cu:99-115
 //   ell_rowmajor_group     cudaSpMVWarpsPerRowELLNTrasposed  src/SpMV_CUDA.cu:116-135
@@ -85,134 +85,20 @@ __global__ __launch_bounds__(1024) void csr_vector_kernel(
     if (lane == 0) y[row] = acc;
 }
 
-// LDS-stream kernel.  Workgroup b owns the consecutive rows
-// [blkRow[b], blkRow[b+1]) whose nnz span is contiguous in AS/JA:
-//   1. every lane loads nnz tid, tid+256, ... of the span (fully coalesced,
-//      non-temporal), gathers x and parks the rounded product in LDS;
-//   2. the rows' segments of the LDS array are summed
-//        SEQ: one thread per row, ascending j  -> bit-identical to the oracle
-//        VEC: L lanes per row (L = largest power of two with L*rows <= 256),
-//             lane-strided partial sums + shuffle tree (LDS segmented reduction)
-// A block that is a single row longer than STREAM_NNZ takes the
-// workgroup-per-row path instead (lane-strided walk, wave shuffle, LDS combine).
 constexpr int STREAM_UNROLL = STREAM_NNZ / WG_THREADS;
 
-template <typename I, bool SEQ>
-__global__ __launch_bounds__(WG_THREADS) void csr_stream_kernel(
-    uint32_t nBlk, const uint32_t* __restrict__ blkRow, const I* __restrict__ IRP,
-    const uint32_t* __restrict__ JA, const double* __restrict__ AS,
-    const double* __restrict__ x, double* __restrict__ y) {
-    __shared__ double prod[STREAM_NNZ];
-    __shared__ double wpart[WG_THREADS / WAVE];
-
-    const uint32_t tid = threadIdx.x;
-    const uint64_t blk = linear_block();
-    if (blk >= nBlk) return;                    // whole workgroup leaves together
-    const uint32_t r0 = blkRow[blk], r1 = blkRow[blk + 1];
-    const I base = IRP[r0], end = IRP[r1];
-
-    if (end - base > (I)STREAM_NNZ) {
-        // ---- long row (the analysis guarantees r1 == r0 + 1)
-        if (SEQ) {
-            // thread-per-row semantics: ONE accumulator, ascending j.  The row is
-            // still streamed coalesced, 2048 products at a time through LDS; lane 0
-            // adds them in order (serial by definition of this launcher).
-            double acc = 0;
-            for (uint64_t c = base; c < (uint64_t)end; c += STREAM_NNZ) {
-                const uint32_t cn = (uint32_t)((uint64_t)end - c < (uint64_t)STREAM_NNZ ? (uint64_t)end - c : (uint64_t)STREAM_NNZ);
-#pragma unroll
-                for (int u = 0; u < STREAM_UNROLL; ++u) {
-                    const uint32_t k = tid + u * WG_THREADS;
-                    if (k < cn) prod[k] = stream_load(AS + c + k) * x[stream_load(JA + c + k)];
-                }
-                __syncthreads();
-                if (tid == 0)
-                    for (uint32_t j = 0; j < cn; ++j) acc += prod[j];
-                __syncthreads();
-            }
-            if (tid == 0) y[r0] = acc;
-            return;
-        }
-        // wavefront semantics: workgroup-per-row, lane-strided partial sums
-        double acc0 = 0, acc1 = 0, acc2 = 0, acc3 = 0;
-        uint64_t j = (uint64_t)base + tid;
-        const uint64_t e64 = end;
-        for (; j + 3 * WG_THREADS < e64; j += 4 * WG_THREADS) {
-            const uint32_t c0 = stream_load(JA + j), c1 = stream_load(JA + j + WG_THREADS),
-                           c2 = stream_load(JA + j + 2 * WG_THREADS), c3 = stream_load(JA + j + 3 * WG_THREADS);
-            const double a0 = stream_load(AS + j), a1 = stream_load(AS + j + WG_THREADS),
-                         a2 = stream_load(AS + j + 2 * WG_THREADS), a3 = stream_load(AS + j + 3 * WG_THREADS);
-            acc0 += a0 * x[c0]; acc1 += a1 * x[c1]; acc2 += a2 * x[c2]; acc3 += a3 * x[c3];
-        }
-        for (; j < e64; j += WG_THREADS) acc0 += stream_load(AS + j) * x[stream_load(JA + j)];
-        double acc = wave_sum((acc0 + acc1) + (acc2 + acc3));
-        if (tid % WAVE == 0) wpart[tid / WAVE] = acc;
-        __syncthreads();
-        if (tid == 0) {
-            double s = wpart[0];
-#pragma unroll
-            for (int w = 1; w < WG_THREADS / WAVE; ++w) s += wpart[w];
-            y[r0] = s;
-        }
-        return;
-    }
-
-    // ---- 1. coalesced span load, gather, products to LDS
-    const uint32_t n = (uint32_t)(end - base);
-    {
-        uint32_t col[STREAM_UNROLL];
-        double   val[STREAM_UNROLL];
-#pragma unroll
-        for (int u = 0; u < STREAM_UNROLL; ++u) {
-            const uint32_t k = tid + u * WG_THREADS;
-            const bool in = k < n;
-            col[u] = in ? stream_load(JA + base + k) : 0u;
-            val[u] = in ? stream_load(AS + base + k) : 0.0;
-        }
-        double xv[STREAM_UNROLL];
-#pragma unroll
-        for (int u = 0; u < STREAM_UNROLL; ++u) xv[u] = x[col[u]];
-#pragma unroll
-        for (int u = 0; u < STREAM_UNROLL; ++u) {
-            const uint32_t k = tid + u * WG_THREADS;
-            if (k < n) prod[k] = val[u] * xv[u];
-        }
-    }
-    __syncthreads();
-
-    // ---- 2. per-row reduction out of LDS
-    const uint32_t R = r1 - r0;
-    if (SEQ) {
-        for (uint32_t r = r0 + tid; r < r1; r += WG_THREADS) {
-            const uint32_t s = (uint32_t)(IRP[r] - base), e = (uint32_t)(IRP[r + 1] - base);
-            double acc = 0;
-            for (uint32_t j = s; j < e; ++j) acc += prod[j];
-            y[r] = acc;
-        }
-    } else {
-        int L = 1;
-        while (L < WAVE && 2u * L * R <= (uint32_t)WG_THREADS) L <<= 1;   // block-uniform
-        const uint32_t rowsPerPass = WG_THREADS / L;
-        const uint32_t g = tid / L, l = tid % L;
-        const uint32_t passes = (R + rowsPerPass - 1) / rowsPerPass;       // same trip count for every lane
-        for (uint32_t p = 0; p < passes; ++p) {
-            const uint32_t rr = p * rowsPerPass + g;
-            const bool live = rr < R;
-            uint32_t s = 0, e = 0;
-            if (live) {
-                s = (uint32_t)(IRP[r0 + rr] - base);
-                e = (uint32_t)(IRP[r0 + rr + 1] - base);
-            }
-            double acc = 0;
-            for (uint32_t j = s + l; j < e; j += L) acc += prod[j];
-            acc = group_sum_rt(acc, L);
-            if (live && l == 0) y[r0 + rr] = acc;
-        }
-    }
-}
-
-// LDS-stream kernel, second generation (default).  Same algorithm as csr_stream_kernel with the
-// latency chain shortened:
+// LDS-stream kernel (default CSR kernel).  Workgroup b owns the consecutive rows of block b, whose nnz span is
+// contiguous in AS/JA:
+//   1. every lane loads nnz tid, tid+256, ... of the span (fully coalesced, non-temporal), gathers x and parks the
+//      rounded product in LDS;
+//   2. the rows' segments of the LDS array are summed
+//        SEQ: one thread per row, ascending j  -> bit-identical to the oracle
+//        VEC: L lanes per row (L = largest power of two with L*rows <= 256), lane-strided partial sums + shuffle
+//             tree (LDS segmented reduction)
+// A block that is a single row longer than STREAM_NNZ takes the workgroup-per-row path instead (lane-strided walk,
+// wave shuffle, LDS combine).  This is the second generation of the kernel; the first (dependent IRP loads in front
+// of the stream) and a third (two row blocks per workgroup, 0-4 % slower) were measured against it and removed
+// (profiles/r01_variants.md).  What the second generation shortened in the latency chain:
 //   * the block table holds {first row, #rows, #nnz} and the block's nnz offset, read with scalar
 //     loads -> no dependent IRP[r0] / IRP[r1] round trips before the stream can start;
 //   * the block's row pointers are loaded together with the AS/JA span and parked in LDS as
@@ -346,166 +232,6 @@ __global__ __launch_bounds__(WG_THREADS) void csr_stream2_kernel(
         }
     }
 }
-
-// Third generation: TWO consecutive row blocks per workgroup.  Both table entries are fetched up front (the table
-// fetch is otherwise a serial ~1 us in front of every block's span loads) and the span loads of the second block are
-// issued BEFORE the first block is reduced, so their HBM latency runs under the LDS reduction.  Only the {col, val,
-// row pointer} registers of the second block are live across the reduction (one LDS buffer, re-used behind a
-// barrier): the register count stays below 64 and 8 workgroups per CU remain resident -- the fully double-buffered
-// persistent form noted below needed 102 VGPRs and was slower.  Long rows keep one workgroup each.
-template <typename I>
-struct StreamSpan { uint32_t col[STREAM_UNROLL]; double val[STREAM_UNROLL]; uint32_t rp0, rp1; };
-
-template <typename I>
-__device__ __forceinline__ void stream3_load(StreamSpan<I>& sp, uint32_t tid, uint32_t r0, uint32_t R, uint32_t n, uint64_t base,
-                                             const I* __restrict__ IRP, const uint32_t* __restrict__ JA, const double* __restrict__ AS) {
-#pragma unroll
-    for (int u = 0; u < STREAM_UNROLL; ++u) {
-        const uint32_t k = tid + u * WG_THREADS;
-        const uint32_t kc = k < n ? k : (n ? n - 1 : 0);        // clamped: no branch around the loads, exact vmcnt
-        sp.col[u] = stream_load(JA + base + kc);
-        sp.val[u] = stream_load(AS + base + kc);
-    }
-    sp.rp0 = sp.rp1 = 0;
-    if (tid < R) sp.rp0 = (uint32_t)((uint64_t)IRP[r0 + tid] - base);
-    if (tid + WG_THREADS < R) sp.rp1 = (uint32_t)((uint64_t)IRP[r0 + tid + WG_THREADS] - base);
-}
-
-template <typename I, bool SEQ>
-__device__ __forceinline__ void stream3_finish(const StreamSpan<I>& sp, uint32_t tid, uint32_t r0, uint32_t R, uint32_t n,
-                                               double* prod, uint16_t* rowOff, const double* __restrict__ x, double* __restrict__ y) {
-    double xv[STREAM_UNROLL];
-#pragma unroll
-    for (int u = 0; u < STREAM_UNROLL; ++u) xv[u] = x[sp.col[u]];
-    if (tid < R) rowOff[tid] = (uint16_t)sp.rp0;
-    if (tid + WG_THREADS < R) rowOff[tid + WG_THREADS] = (uint16_t)sp.rp1;
-    if (tid == 0) rowOff[R] = (uint16_t)n;
-#pragma unroll
-    for (int u = 0; u < STREAM_UNROLL; ++u) {
-        const uint32_t k = tid + u * WG_THREADS;
-        if (k < n) prod[k] = sp.val[u] * xv[u];
-    }
-}
-
-template <bool SEQ>
-__device__ __forceinline__ void stream3_reduce(uint32_t tid, uint32_t r0, uint32_t R, const double* prod, const uint16_t* rowOff,
-                                               double* __restrict__ y) {
-    if (SEQ) {
-        for (uint32_t rr = tid; rr < R; rr += WG_THREADS) {
-            const uint32_t s = rowOff[rr], e = rowOff[rr + 1];
-            double acc = 0;
-            for (uint32_t j = s; j < e; ++j) acc += prod[j];
-            y[r0 + rr] = acc;
-        }
-    } else {
-        int L = 1;
-        while (L < WAVE && 2u * L * R <= (uint32_t)WG_THREADS) L <<= 1;
-        const uint32_t rowsPerPass = WG_THREADS / L;
-        const uint32_t g = tid / L, l = tid % L;
-        const uint32_t passes = (R + rowsPerPass - 1) / rowsPerPass;
-        for (uint32_t p = 0; p < passes; ++p) {
-            const uint32_t rr = p * rowsPerPass + g;
-            const bool live = rr < R;
-            uint32_t s = 0, e = 0;
-            if (live) { s = rowOff[rr]; e = rowOff[rr + 1]; }
-            double acc = 0;
-            for (uint32_t j = s + l; j < e; j += L) acc += prod[j];
-            acc = group_sum_rt(acc, L);
-            if (live && l == 0) y[r0 + rr] = acc;
-        }
-    }
-}
-
-template <typename I, bool SEQ>
-__global__ __launch_bounds__(WG_THREADS, 8 * 256 / WG_THREADS) void csr_stream3_kernel(
-    uint32_t nBlk, uint32_t nLong, const uint4* __restrict__ blkInfo, const uint64_t* __restrict__ blkBase,
-    const I* __restrict__ IRP, const uint32_t* __restrict__ JA,
-    const double* __restrict__ AS, const double* __restrict__ x, double* __restrict__ y) {
-    __shared__ double   prod[STREAM_NNZ];
-    __shared__ uint16_t rowOff[STREAM2_MAX_ROWS + 1];
-    __shared__ double   wpart[WG_THREADS / WAVE];
-
-    const uint32_t tid = threadIdx.x;
-    const uint64_t wg = linear_block();
-    const uint64_t nPairs = ((uint64_t)(nBlk - nLong) + 1) / 2;
-    if (wg >= nLong + nPairs) return;
-    if (wg < nLong) {
-        // ---- long row (single row of n > STREAM_NNZ entries): as in the second generation
-        const uint4 info = blkInfo[wg];
-        const uint32_t r0 = info.x, n = info.z;
-        const uint64_t base = blkBase[wg], end = base + n;
-        if (SEQ) {
-            double acc = 0;
-            for (uint64_t c = base; c < end; c += STREAM_NNZ) {
-                const uint32_t cn = (uint32_t)(end - c < (uint64_t)STREAM_NNZ ? end - c : (uint64_t)STREAM_NNZ);
-#pragma unroll
-                for (int u = 0; u < STREAM_UNROLL; ++u) {
-                    const uint32_t k = tid + u * WG_THREADS;
-                    if (k < cn) prod[k] = stream_load(AS + c + k) * x[stream_load(JA + c + k)];
-                }
-                __syncthreads();
-                if (tid == 0)
-                    for (uint32_t j = 0; j < cn; ++j) acc += prod[j];
-                __syncthreads();
-            }
-            if (tid == 0) y[r0] = acc;
-            return;
-        }
-        double acc0 = 0, acc1 = 0, acc2 = 0, acc3 = 0;
-        uint64_t j = base + tid;
-        for (; j + 3 * WG_THREADS < end; j += 4 * WG_THREADS) {
-            const uint32_t c0 = stream_load(JA + j), c1 = stream_load(JA + j + WG_THREADS),
-                           c2 = stream_load(JA + j + 2 * WG_THREADS), c3 = stream_load(JA + j + 3 * WG_THREADS);
-            const double a0 = stream_load(AS + j), a1 = stream_load(AS + j + WG_THREADS),
-                         a2 = stream_load(AS + j + 2 * WG_THREADS), a3 = stream_load(AS + j + 3 * WG_THREADS);
-            acc0 += a0 * x[c0]; acc1 += a1 * x[c1]; acc2 += a2 * x[c2]; acc3 += a3 * x[c3];
-        }
-        for (; j < end; j += WG_THREADS) acc0 += stream_load(AS + j) * x[stream_load(JA + j)];
-        double acc = wave_sum((acc0 + acc1) + (acc2 + acc3));
-        if (tid % WAVE == 0) wpart[tid / WAVE] = acc;
-        __syncthreads();
-        if (tid == 0) {
-            double s = wpart[0];
-#pragma unroll
-            for (int w = 1; w < WG_THREADS / WAVE; ++w) s += wpart[w];
-            y[r0] = s;
-        }
-        return;
-    }
-    // ---- a pair of row-ordered blocks; pairs are dealt to the XCDs in contiguous ranges (as the blocks were)
-    uint64_t pr;
-    {
-        const uint64_t q = wg - nLong, a = nPairs / 8, rem = nPairs % 8, xcd = q % 8;
-        pr = xcd * a + (xcd < rem ? xcd : rem) + q / 8;
-    }
-    const uint64_t bA = nLong + 2 * pr, bB = bA + 1;
-    const bool hasB = bB < nBlk;                     // uniform
-    const uint4 infoA = blkInfo[bA];
-    const uint64_t baseA = blkBase[bA];
-    const uint4 infoB = hasB ? blkInfo[bB] : make_uint4(0, 0, 0, 0);
-    const uint64_t baseB = hasB ? blkBase[bB] : baseA;
-
-    StreamSpan<I> sp;
-    stream3_load<I>(sp, tid, infoA.x, infoA.y, infoA.z, baseA, IRP, JA, AS);
-    stream3_finish<I, SEQ>(sp, tid, infoA.x, infoA.y, infoA.z, prod, rowOff, x, y);
-    if (hasB) stream3_load<I>(sp, tid, infoB.x, infoB.y, infoB.z, baseB, IRP, JA, AS);      // in flight during A's reduction
-    __syncthreads();
-    stream3_reduce<SEQ>(tid, infoA.x, infoA.y, prod, rowOff, y);
-    if (!hasB) return;
-    __syncthreads();                                 // A's LDS image is dead
-    stream3_finish<I, SEQ>(sp, tid, infoB.x, infoB.y, infoB.z, prod, rowOff, x, y);
-    __syncthreads();
-    stream3_reduce<SEQ>(tid, infoB.x, infoB.y, prod, rowOff, y);
-}
-
-// (A persistent, software-pipelined form -- fixed grid, next block's span prefetched into a second
-//  register set while the current block is gathered and reduced -- was built and measured: 102 VGPRs
-//  -> 4 workgroups/CU, and slower everywhere (band 512: 0.83 vs 0.57 ms; serial-order variant 2.8 ms
-//  because long rows pin their workgroup).  With 8 resident workgroups per CU the hardware scheduler
-//  already overlaps the phases of different blocks.  Not kept; see DESIGN.md section 7.
-//  Also measured and dropped: lanes owning PAIRS of entries (16-B AS / 8-B JA loads from an even-aligned
-//  span start): 2-7 % slower on every workload (band 512: 0.582 vs 0.567 ms) -- fewer, wider vector loads
-//  do not help while the gather instructions dominate the memory pipe, and adjacent LDS stores conflict.)
 
 // ----------------------------------------------------------------------------------- ELL
 // Column-major ("transposed") + pitched, one thread per row: lane i of a wave

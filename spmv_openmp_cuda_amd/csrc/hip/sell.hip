@@ -199,7 +199,7 @@ int buildSellT(DevMat* d, SellFormat* f) {
     SELL_TRY(hipMalloc(&f->sliceOff, ((size_t)f->nSlices + 1) * 8));
     const dim3 gRows = grid2d((padded + 255) / 256, 256);
     uint32_t sigma = SELL_SIGMA_DEFAULT;
-    if (const char* e = getenv("SPMV_SELL_SIGMA")) { const long v = atol(e); if (v >= 64) sigma = (uint32_t)v; }
+    if (const char* e = getenv("SPMV_SELL_SIGMA")) { const long v = atol(e); if (v >= 64) sigma = (uint32_t)(v / 64 * 64); }   // whole slices: a window that ends inside a slice would break "first row of a slice is its longest"
     hipLaunchKernelGGL((sell_keys_kernel<I>), gRows, dim3(256), 0, nullptr, M, padded, sigma, IRP, keys.as<uint64_t>(), rows.as<uint32_t>());
     size_t tmpBytes = 0;
     SELL_TRY(rocprim::radix_sort_pairs(nullptr, tmpBytes, keys.as<uint64_t>(), keysOut.as<uint64_t>(), rows.as<uint32_t>(), f->perm,

@@ -64,8 +64,6 @@ struct StripeFormat {
     uint32_t* stepBase = nullptr;                   // narrow only: [nSteps] first column of the step
     uint32_t* binRow = nullptr;                     // [B+1] first row of each bin
     uint32_t* binStep = nullptr;                    // [B+1] first step of each bin
-    void*     sync = nullptr;                       // SbSync: progress slots of the workgroups, per XCD (zeroed before every launch)
-    uint32_t  ticketsPerBin = 0;                    // batches of the longest bin
     size_t    bytes = 0;
     double    buildMs = 0;
 };
@@ -216,96 +214,20 @@ __device__ __forceinline__ void sb_add(double* yb, const SbStream& s, const SbGa
     }
 }
 
-// ---- keeping the workgroups of one XCD together -------------------------------------------------------------
-// The gather is an L2 hit only while the workgroups resident on one XCD stay within ~1-2 MB of x of each other
-// (4 MiB of L2 minus what the wavefronts' own loads in flight span).  Equal entry counts per bin give equal
-// AVERAGE speeds, but a workgroup that falls behind the others finds its lines evicted, runs slower still and
-// never comes back; and a second round of bins started as the first round's workgroups ended, 50-90 us apart.
-// So the kernel is persistent (one workgroup per CU walks the bins w, w + G, ...: every round starts where the
-// last one ended) and the workgroups of an XCD throttle their LEADERS: each publishes its progress -- tickets
-// handed out so far, counted over all of its bins -- in a slot of a per-XCD line of global memory, and a
-// wavefront whose new ticket is more than `window` ahead of the XCD's slowest workgroup sleeps until that one
-// has caught up.  The slowest workgroup never waits, workgroups register when they start (one not yet resident
-// is not waited for) and mark their slot done when they leave, and a wait that exceeds its spin budget switches
-// the throttle off for that workgroup: the protocol changes speed, never results, and cannot hang.
-// State is zeroed by a memset node in front of every launch.
-struct SbSync { uint32_t line[8][64]; };            // per XCD: words 0..62 progress slots, word 63 the number of registered workgroups
-constexpr uint32_t SB_SYNC_OFF = 0xFFFFFFFFu;
-constexpr uint32_t SB_SYNC_SLOTS = 63;
-#ifndef SPMV_SB_BEAT
-#define SPMV_SB_BEAT 8
-#endif
-constexpr uint32_t SB_SYNC_BEAT = SPMV_SB_BEAT;
-constexpr uint32_t SB_SPIN_BUDGET = 1u << 14;       // sleeps of ~0.4 us: a few ms in total, then the workgroup stops throttling
-
-struct SbLds { uint32_t ctr, lim, slot, budget; };   // behind the bin's y in LDS
-
-__device__ __forceinline__ uint32_t sb_wave_min(uint32_t v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v = min(v, (uint32_t)__shfl_xor((int)v, off, 64));
-    return v;
-}
-
-// Progress words are written with PLAIN stores and read with sc1 loads: writers and readers of a line sit on one XCD
-// (slots are handed out per XCC id), whose L2 is their point of coherence -- a plain store is written through the
-// L1 and stays in that L2, an sc1 load bypasses the L1 and is served by it.  (sc1 / atomic stores DROP the line from
-// the L2: every reader then waited for the fabric, 5 ms instead of 0.9 on c3.)
-// (A volatile store compiles to `flat_store sc0 sc1` + `s_waitcnt vmcnt(0)` -- a full drain per publish; a relaxed
-// workgroup-scope atomic store is the plain `global_store_dword` that is wanted and cannot be optimised away.)
-__device__ __forceinline__ void sb_publish(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
-
-// the XCD's progress line as loaded by 64 lanes -> slowest registered workgroup's progress + window
-__device__ __forceinline__ uint32_t sb_limit(uint32_t v, uint32_t lane, uint32_t window) {
-    const uint32_t cnt = (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
-    if (lane >= cnt || lane >= SB_SYNC_SLOTS) v = SB_SYNC_OFF;
-    const uint32_t m = sb_wave_min(v);
-    return m > SB_SYNC_OFF - window ? SB_SYNC_OFF : m + window;
-}
-
-// Next ticket of the workgroup (one LDS atomic by lane 0, broadcast).  With the throttle on: publishes the progress,
-// waits while the ticket is beyond the limit the workgroup last computed, and issues the load of the XCD's progress
-// line whose result the caller hands to sb_refresh() a little later (after its stream loads are issued: the limit
-// is refreshed once per ticket without any wavefront waiting for the round trip).
-__device__ __forceinline__ uint32_t sb_ticket(SbLds* l, uint32_t lane, SbSync* sync, uint32_t p0, uint32_t window, uint32_t& pend, bool& fresh) {
+// next ticket of the workgroup (one LDS atomic by lane 0, broadcast)
+__device__ __forceinline__ uint32_t sb_ticket(uint32_t* ctr, uint32_t lane) {
     uint32_t t = 0;
-    if (lane == 0) t = atomicAdd(&l->ctr, 1u);
-    t = (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
-    const uint32_t slot = (uint32_t)__builtin_amdgcn_readfirstlane((int)l->slot);
-    pend = SB_SYNC_OFF;
-    fresh = false;
-    if (slot != SB_SYNC_OFF) {                       // wavefront-uniform
-        const uint32_t P = p0 + t, xcc = slot / 64;
-        const bool beat = (t % SB_SYNC_BEAT) == 0;   // publish and refresh on every SB_SYNC_BEAT-th ticket only: the line is hot
-        if (beat && lane == 0) sb_publish(&sync->line[xcc][slot % 64], P);
-        uint32_t lim = (uint32_t)__builtin_amdgcn_readfirstlane((int)l->lim);
-        uint32_t spins = 0;
-        while (P > lim) {                            // too far ahead of the XCD's slowest workgroup: re-read, sleep
-            lim = sb_limit(__hip_atomic_load(&sync->line[xcc][lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), lane, window);
-            if (lane == 0) l->lim = lim;
-            if (P <= lim) break;
-            if (++spins >= 64) {                     // long wait: charge the workgroup's budget, give up when it is spent
-                spins = 0;
-                uint32_t left = 0;
-                if (lane == 0) left = atomicSub(&l->budget, 64u);
-                left = (uint32_t)__builtin_amdgcn_readfirstlane((int)left);
-                if (left <= 64u || left > SB_SPIN_BUDGET) {
-                    if (lane == 0) { l->slot = SB_SYNC_OFF; sb_publish(&sync->line[xcc][slot % 64], SB_SYNC_OFF); }
-                    return t;
-                }
-            }
-            __builtin_amdgcn_s_sleep(16);
-        }
-        if (beat) { pend = __hip_atomic_load(&sync->line[xcc][lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); fresh = true; }
-    }
-    return t;
+    if (lane == 0) t = atomicAdd(ctr, 1u);
+    return (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
 }
 
-__device__ __forceinline__ void sb_refresh(SbLds* l, uint32_t lane, SbSync* sync, uint32_t window, uint32_t pend, bool fresh) {
-    if (fresh) {                                     // wavefront-uniform
-        const uint32_t lim = sb_limit(pend, lane, window);
-        if (lane == 0 && l->slot != SB_SYNC_OFF) l->lim = lim;
-    }
-}
+// Tried on top of this and removed again (commit 6ecc064, logs profiles/r02_stripes_throttle_*): keeping the 32
+// workgroups of an XCD inside a window of each other by throttling the leaders (per-XCD progress line in global
+// memory, plain stores / sc1 loads, refreshed asynchronously every 8th ticket) and aligning the rounds of bins.
+// It does what it says -- workgroups within +-5 us of each other over a 480 us bin, rounds starting together --
+// and buys nothing: c3 0.98-1.03 ms throttled against 0.93 free-running, band +-16 Ki 0.48 against 0.41.  A
+// workgroup in a tight pack gathers no faster, because the gather is bounded by the lines a CU's L1 can have in
+// flight to L2 (~0.27-0.38 lines per clock and CU here and in scripts/microbench_gather.hip), not by L2 misses.
 
 #ifdef SPMV_SB_DEBUG          // tuning builds only: per-bin placement and progress stamps (100 MHz clock)
 __device__ uint64_t sb_dbg[8 * 8192];
@@ -317,26 +239,13 @@ template <bool WIDE>
 __global__ __launch_bounds__(SB_THREADS) void sb_spmv_kernel(
     uint32_t B, const uint32_t* __restrict__ binRow, const uint32_t* __restrict__ binStep,
     const double* __restrict__ val, const uint32_t* __restrict__ cr, const uint16_t* __restrict__ lrowW,
-    const uint32_t* __restrict__ stepBase, const double* __restrict__ x, double* __restrict__ y, uint32_t ldsRows,
-    SbSync* sync, uint32_t window, uint32_t ticketsPerBin) {
-    extern __shared__ double yb[];                  // ldsRows doubles (rows of the highest bin), then SbLds
-    SbLds* l = reinterpret_cast<SbLds*>(yb + ldsRows);
+    const uint32_t* __restrict__ stepBase, const double* __restrict__ x, double* __restrict__ y, uint32_t ldsRows) {
+    extern __shared__ double yb[];                  // ldsRows doubles (rows of the highest bin), then the ticket counter
+    uint32_t* ctr = reinterpret_cast<uint32_t*>(yb + ldsRows);
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x / 64)), lane = threadIdx.x % 64;
-    if (threadIdx.x == 0) {
-        uint32_t slot = SB_SYNC_OFF;
-        if (sync) {                                  // register with the workgroups of this XCD
-            uint32_t xcc;
-            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-            xcc &= 7u;
-            const uint32_t k = atomicAdd(&sync->line[xcc][63], 1u);
-            if (k < SB_SYNC_SLOTS) slot = xcc * 64 + k;
-        }
-        l->slot = slot;
-        l->lim = window;
-        l->budget = SB_SPIN_BUDGET;
-    }
-    uint32_t p0 = 0;                                 // tickets of this workgroup's earlier bins
-    for (uint64_t bin = lin_block(); bin < B; bin += (uint64_t)gridDim.x * gridDim.y, p0 += ticketsPerBin) {
+    // persistent: one workgroup per CU walks the bins w, w + G, ... (its bin of y fills the LDS, so no second
+    // workgroup could share the CU anyway, and a bin starts the moment the previous one is stored)
+    for (uint64_t bin = lin_block(); bin < B; bin += (uint64_t)gridDim.x * gridDim.y) {
         const uint32_t row0 = binRow[bin], R = binRow[bin + 1] - row0;
         const uint32_t s0 = binStep[bin], s1 = binStep[bin + 1];
 #ifdef SPMV_SB_DEBUG
@@ -356,12 +265,10 @@ __global__ __launch_bounds__(SB_THREADS) void sb_spmv_kernel(
             sb_stream<WIDE>(c, wave + 2 * SB_WAVES, s0, s1, lane, val, cr, lrowW, stepBase);
         }
         for (uint32_t k = threadIdx.x; k < R; k += SB_THREADS) yb[k] = 0.0;
-        if (threadIdx.x == 0) l->ctr = 3 * SB_WAVES;
+        if (threadIdx.x == 0) *ctr = 3 * SB_WAVES;
         __syncthreads();
         if (s1 > s0) {
             sb_gather<WIDE>(g0, a, x);
-            uint32_t pend, tk;
-            bool fresh;
 #ifdef SPMV_SB_DEBUG
             const uint32_t quarter = (s1 - s0) / 4;
             uint32_t nextMark = 1;
@@ -371,13 +278,11 @@ __global__ __launch_bounds__(SB_THREADS) void sb_spmv_kernel(
 #define SB_PROGRESS(S) do { } while (0)
 #endif
             // one stage: CUR is added, NXT gathered, FAR (the set CUR's predecessor freed) streamed with a fresh ticket
-#define SB_STAGE(CUR, NXT, FAR, GC, GN)                                                                                \
-            if (CUR.first >= s1) break;                                                                                \
-            tk = sb_ticket(l, lane, sync, p0, window, pend, fresh);      /* the progress-line load is the OLDEST of the stage */ \
-            sb_gather<WIDE>(GN, NXT, x);                                                                               \
-            sb_stream<WIDE>(FAR, tk, s0, s1, lane, val, cr, lrowW, stepBase);                                          \
-            sb_refresh(l, lane, sync, window, pend, fresh);                                                             \
-            sb_add<WIDE>(yb, CUR, GC, s1);                                                                             \
+#define SB_STAGE(CUR, NXT, FAR, GC, GN)                                                            \
+            if (CUR.first >= s1) break;                                                            \
+            sb_gather<WIDE>(GN, NXT, x);                                                           \
+            sb_stream<WIDE>(FAR, sb_ticket(ctr, lane), s0, s1, lane, val, cr, lrowW, stepBase);    \
+            sb_add<WIDE>(yb, CUR, GC, s1);                                                         \
             SB_PROGRESS(CUR);
             for (;;) {
                 SB_STAGE(a, b, d, g0, g1)
@@ -395,8 +300,6 @@ __global__ __launch_bounds__(SB_THREADS) void sb_spmv_kernel(
         for (uint32_t k = threadIdx.x; k < R; k += SB_THREADS) y[(uint64_t)row0 + k] = yb[k];
         __syncthreads();                             // the next bin zeroes yb
     }
-    if (threadIdx.x == 0 && l->slot != SB_SYNC_OFF)  // nobody waits for a workgroup that has left
-        sb_publish(&sync->line[l->slot / 64][l->slot % 64], SB_SYNC_OFF);
 }
 
 #define SB_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { fprintf(stderr, "libspmvhip: stripes: %s: %s\n", #expr, hipGetErrorString(e_)); return EXIT_FAILURE; } } while (0)
@@ -445,7 +348,7 @@ bool planBins(const std::vector<uint64_t>& irp, uint64_t M, uint32_t rMax, std::
 void freeStripes(StripeFormat* f) {
     if (!f) return;
     (void)hipFree(f->val); (void)hipFree(f->cr); (void)hipFree(f->lrowW); (void)hipFree(f->stepBase);
-    (void)hipFree(f->binRow); (void)hipFree(f->binStep); (void)hipFree(f->sync);
+    (void)hipFree(f->binRow); (void)hipFree(f->binStep);
     delete f;
 }
 
@@ -531,17 +434,14 @@ int buildStripes(DevMat* d) {
     binStart[B] = nnz;
     if (steps >= (1ull << 32) - (1u << 16)) { fprintf(stderr, "libspmvhip: stripes: too many steps\n"); return EXIT_FAILURE; }
     binStep[B] = (uint32_t)steps;
-    uint32_t maxBinSteps = 0;
-    for (uint32_t b = 0; b < B; ++b) maxBinSteps = std::max(maxBinSteps, binStep[b + 1] - binStep[b]);
     { std::vector<uint64_t>().swap(irp); }
 
     StripeFormat* f = new StripeFormat;
     f->B = B; f->R = R; f->nnz = nnz; f->nSteps = steps;
-    f->ticketsPerBin = (maxBinSteps + SB_DEPTH - 1) / SB_DEPTH;
     auto fail = [&](const char* what) { fprintf(stderr, "libspmvhip: stripes: %s failed\n", what); freeStripes(f); return EXIT_FAILURE; };
     TempBuf keys, keysOut, idx, perm, rowOf, sortTmp, dBinStart, dOverflow;
     if (hipMalloc(&f->binRow, ((size_t)B + 1) * 4) || hipMalloc(&f->binStep, ((size_t)B + 1) * 4) || dBinStart.alloc(((size_t)B + 1) * 8) ||
-        dOverflow.alloc(4) || hipMalloc(&f->sync, sizeof(SbSync)))
+        dOverflow.alloc(4))
         return fail("table allocation");
     if (hipMemcpy(f->binRow, binRow.data(), ((size_t)B + 1) * 4, hipMemcpyHostToDevice) ||
         hipMemcpy(f->binStep, binStep.data(), ((size_t)B + 1) * 4, hipMemcpyHostToDevice) ||
@@ -581,8 +481,8 @@ int buildStripes(DevMat* d) {
     }
     static bool attrSet = false;
     if (!attrSet) {
-        if (hipFuncSetAttribute((const void*)sb_spmv_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, SB_R_MAX * 8 + sizeof(SbLds)) ||
-            hipFuncSetAttribute((const void*)sb_spmv_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, SB_R_MAX * 8 + sizeof(SbLds)))
+        if (hipFuncSetAttribute((const void*)sb_spmv_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, SB_R_MAX * 8 + 16) ||
+            hipFuncSetAttribute((const void*)sb_spmv_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, SB_R_MAX * 8 + 16))
             return fail("kernel attribute");
         attrSet = true;
     }
@@ -606,27 +506,14 @@ int enqueueStripes(DevMat* d, const double* x, double* y, hipStream_t stream) {
         if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return EXIT_FAILURE;
         cus = std::max(1, prop.multiProcessorCount);
     }
-    // tuning knobs (environment, read once): SPMV_SB_SYNC=0 switches the leader throttle off, SPMV_SB_WINDOW is its
-    // width in entries
-    static int syncOn = -1;
-    static uint32_t windowEntries = 8192;
-    if (syncOn < 0) {
-        syncOn = 1;
-        if (const char* e = getenv("SPMV_SB_SYNC")) syncOn = atoi(e) != 0;
-        if (const char* e = getenv("SPMV_SB_WINDOW")) { const long v = atol(e); if (v >= 128 && v <= (1l << 30)) windowEntries = (uint32_t)v; }
-    }
     const uint32_t grid = std::min<uint32_t>(f->B, (uint32_t)cus);
-    const bool sync = syncOn && grid > 1;
-    const uint32_t window = std::max<uint32_t>(1, windowEntries / (SB_DEPTH * SB_STEP));
-    SbSync* st = sync ? static_cast<SbSync*>(f->sync) : nullptr;
-    if (st && hipMemsetAsync(st, 0, sizeof(SbSync), stream) != hipSuccess) return EXIT_FAILURE;
-    const size_t lds = (size_t)8 * f->R + sizeof(SbLds);
+    const size_t lds = (size_t)8 * f->R + 16;
     if (f->wide)
         hipLaunchKernelGGL(sb_spmv_kernel<true>, dim3(grid), dim3(SB_THREADS), lds, stream, f->B, f->binRow, f->binStep, f->val, f->cr,
-                           f->lrowW, f->stepBase, x, y, f->R, st, window, f->ticketsPerBin);
+                           f->lrowW, f->stepBase, x, y, f->R);
     else
         hipLaunchKernelGGL(sb_spmv_kernel<false>, dim3(grid), dim3(SB_THREADS), lds, stream, f->B, f->binRow, f->binStep, f->val, f->cr,
-                           f->lrowW, f->stepBase, x, y, f->R, st, window, f->ticketsPerBin);
+                           f->lrowW, f->stepBase, x, y, f->R);
     return hipGetLastError() == hipSuccess ? EXIT_SUCCESS : EXIT_FAILURE;
 }
 

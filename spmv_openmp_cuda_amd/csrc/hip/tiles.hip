@@ -96,6 +96,9 @@ struct TileFormat {
     uint32_t* pushFail = nullptr;                   // set by the push kernel when a flag never arrived
     uint32_t  epoch = 0;
     size_t    bytes = 0;
+    spmvTilesOpts opts{0, 0, -1, 0};                // what the format was built with (0 / -1 = automatic)
+    uint32_t  chunk = 0;                            // phase-1 work item size in entries actually used
+    double    buildMs = 0;                          // device time of the one-time build
 };
 
 struct TileDst { double* p[SPMV_MAX_PEERS]; uint32_t n; };
@@ -568,41 +571,61 @@ struct TempBuf {
 // addresses matters when a matrix is processed as several row groups whose products fit the 256 MiB Infinity
 // Cache: the lines are overwritten while still cached instead of being written back to HBM and re-allocated
 // (scripts/microbench_mall.hip: write-then-read of a 128 MiB buffer 6.6 TB/s, of a 2 GiB one 4.9-5.1 TB/s).
-struct ProdWorkspace { double* p = nullptr; size_t cap = 0; };
+struct ProdWorkspace { double* p = nullptr; size_t cap = 0; hipEvent_t lastUse = nullptr; hipStream_t lastStream = nullptr; bool used = false; };   // lastStream: where the products were last written or read
 static ProdWorkspace g_prod[16];
 
-static double* prodWorkspace(size_t n, bool grow) {
+static ProdWorkspace* prodSlot() {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
-    ProdWorkspace& w = g_prod[dev];
-    if (n <= w.cap || !grow) return n <= w.cap ? w.p : nullptr;
+    return &g_prod[dev];
+}
+
+static double* prodWorkspace(size_t n, bool grow) {
+    ProdWorkspace* w = prodSlot();
+    if (!w) return nullptr;
+    if (n <= w->cap || !grow) return n <= w->cap ? w->p : nullptr;
     (void)hipDeviceSynchronize();                   // nothing may still read the old buffer
-    if (w.p) (void)hipFree(w.p);
-    w.p = nullptr; w.cap = 0;
-    if (hipMalloc(&w.p, n * sizeof(double)) != hipSuccess) { w.p = nullptr; return nullptr; }
-    w.cap = n;
-    return w.p;
+    if (w->p) (void)hipFree(w->p);
+    w->p = nullptr; w->cap = 0;
+    if (hipMalloc(&w->p, n * sizeof(double)) != hipSuccess) { w->p = nullptr; return nullptr; }
+    w->cap = n;
+    return w->p;
+}
+
+// The workspace is shared by every matrix of the device: a phase 1 must not start before the phase 2 that reads the
+// previous products has finished.  On one stream that is stream order.  When the stream changes (spmvHipSetStream, or
+// two handles driven from two streams) the new stream first waits for everything enqueued on the previous one.
+static int prodHandover(hipStream_t stream) {
+    ProdWorkspace* w = prodSlot();
+    if (!w) return EXIT_FAILURE;
+    if (w->used && w->lastStream != stream) {
+        if (!w->lastUse && hipEventCreateWithFlags(&w->lastUse, hipEventDisableTiming) != hipSuccess) return EXIT_FAILURE;
+        if (hipEventRecord(w->lastUse, w->lastStream) != hipSuccess || hipStreamWaitEvent(stream, w->lastUse, 0) != hipSuccess) {
+            (void)hipGetLastError();                // the previous stream is gone: wait for the device instead
+            if (hipDeviceSynchronize() != hipSuccess) return EXIT_FAILURE;
+        }
+    }
+    w->lastStream = stream;
+    w->used = true;
+    return EXIT_SUCCESS;
 }
 
 void freeTilesWorkspace() {
     int keep = 0;
     (void)hipGetDevice(&keep);
     for (int d = 0; d < 16; ++d)
-        if (g_prod[d].p) { (void)hipSetDevice(d); (void)hipFree(g_prod[d].p); g_prod[d] = ProdWorkspace{}; }
+        if (g_prod[d].p || g_prod[d].lastUse) {
+            (void)hipSetDevice(d);
+            if (g_prod[d].p) (void)hipFree(g_prod[d].p);
+            if (g_prod[d].lastUse) (void)hipEventDestroy(g_prod[d].lastUse);
+            g_prod[d] = ProdWorkspace{};
+        }
     (void)hipSetDevice(keep);
 }
 
-static bool     g_taper = false;
-int setTilesTaper(int on) { g_taper = on != 0; return EXIT_SUCCESS; }
 uint64_t tilesBinRow(const DevMat* d, uint32_t bin) {
     if (!d->tiles) return 0;
     return bin >= d->tiles->B ? d->M : std::min<uint64_t>(d->M, d->tiles->bins.row0(bin));
-}
-static uint32_t g_rowsPerBin = 0;                  // 0 = automatic
-int setTilesRowsPerBin(uint32_t rows) {
-    if (rows != 0 && (rows < 64 || rows > PB_R_MAX)) return EXIT_FAILURE;
-    g_rowsPerBin = rows;
-    return EXIT_SUCCESS;
 }
 
 void freeTiles(TileFormat* t) {
@@ -612,14 +635,32 @@ void freeTiles(TileFormat* t) {
     delete t;
 }
 
-int buildTiles(DevMat* d) {
-    if (d->tiles) return EXIT_SUCCESS;
+// `opts` == nullptr: automatic format, kept if one exists.  Explicit options: an existing format is replaced.
+int buildTiles(DevMat* d, const spmvTilesOpts* opts) {
+    if (d->tiles && !opts) return EXIT_SUCCESS;
     if (d->kind != Kind::CSR) return EXIT_FAILURE;
+    const spmvTilesOpts o = opts ? *opts : spmvTilesOpts{0, 0, -1, 0};
+    if (o.rowsPerBin != 0 && (o.rowsPerBin < 64 || o.rowsPerBin > PB_R_MAX)) {
+        fprintf(stderr, "libspmvhip: tiles: rowsPerBin = %u is not 0 (automatic) or 64..%u\n", o.rowsPerBin, PB_R_MAX);
+        return EXIT_FAILURE;
+    }
+    if (o.chunk != 0 && (o.chunk < 4096 || o.chunk > (1u << 24))) {
+        fprintf(stderr, "libspmvhip: tiles: chunk = %u is not 0 (automatic) or 4096..2^24\n", o.chunk);
+        return EXIT_FAILURE;
+    }
+    if (d->tiles) { freeTiles(d->tiles); d->tiles = nullptr; }
     const uint64_t nnz = d->NZ, M = d->M, N = d->N;
     if (nnz >= IRP32_LIMIT || nnz == 0) { fprintf(stderr, "libspmvhip: tiles: nnz = %lu unsupported (needs 0 < nnz < 2^32)\n", (unsigned long)nnz); return EXIT_FAILURE; }
     const uint64_t S64 = (N + PB_C - 1) / PB_C;
     if (S64 > 65535) { fprintf(stderr, "libspmvhip: tiles: %lu columns exceed 65535 slices\n", (unsigned long)N); return EXIT_FAILURE; }
     TileFormat* t = new TileFormat;
+    struct Guard { TileFormat*& t; ~Guard() { if (t) freeTiles(t); } } guard{t};      // every early return frees the half-built format
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    PB_TRY(hipEventCreate(&ev0));
+    PB_TRY(hipEventCreate(&ev1));
+    struct EvGuard { hipEvent_t a, b; ~EvGuard() { (void)hipEventDestroy(a); (void)hipEventDestroy(b); } } evGuard{ev0, ev1};
+    PB_TRY(hipEventRecord(ev0, nullptr));
+    t->opts = o;
     t->S = (uint32_t)S64;
     // Rows per bin R (any value up to PB_R_MAX, not a power of two): phase 2 runs ONE workgroup per CU at a time (its
     // bin of y fills the LDS), so the bins are processed in rounds of PB_CUS and a partly filled last round leaves
@@ -636,11 +677,11 @@ int buildTiles(DevMat* d) {
             R = std::min(R, PB_R_MAX);
         }
     }
-    if (g_rowsPerBin) R = g_rowsPerBin;                                                              // spmvHipSetTilesRowsPerBin
+    if (o.rowsPerBin) R = o.rowsPerBin;
     if (const char* e = getenv("SPMV_PB_ROWS")) { const int v = atoi(e); if (v >= 64 && v <= (int)PB_R_MAX) R = (uint32_t)v; }   // tuning only
     t->bins = BinMap{};
     t->bins.c = R;
-    bool taper = g_taper;
+    bool taper = o.taper != 0;
     if (const char* e = getenv("SPMV_PB_TAPER")) taper = atoi(e) != 0;                                 // tuning only
     if (taper && M >= (uint64_t)4 * PB_CUS * 1024) {
         // one round of quarter-height bins first and last, full-height bins (a multiple of PB_CUS of them) between
@@ -660,10 +701,10 @@ int buildTiles(DevMat* d) {
     t->B = t->bins.z2 >= M ? t->bins.n1 + t->bins.n2 : t->bins.n1 + t->bins.n2 + (uint32_t)((M - t->bins.z2 + t->bins.c - 1) / t->bins.c);
     t->nnz = nnz;
     const uint64_t nTiles = (uint64_t)t->S * t->B;
-    if (nTiles >= (1ull << 32) - 2) { fprintf(stderr, "libspmvhip: tiles: too many tiles\n"); delete t; return EXIT_FAILURE; }
+    if (nTiles >= (1ull << 32) - 2) { fprintf(stderr, "libspmvhip: tiles: too many tiles\n"); return EXIT_FAILURE; }
 
     TempBuf rowOf, keys, keysOut, idx, perm, sortTmp, tileStart;
-    auto fail = [&](const char* what) { fprintf(stderr, "libspmvhip: tiles: %s failed\n", what); freeTiles(t); return EXIT_FAILURE; };
+    auto fail = [&](const char* what) { fprintf(stderr, "libspmvhip: tiles: %s failed\n", what); return EXIT_FAILURE; };
     if (rowOf.alloc(nnz * 4) || keys.alloc(nnz * 2) || keysOut.alloc(nnz * 2) || idx.alloc(nnz * 4) || perm.alloc(nnz * 4) ||
         tileStart.alloc((nTiles + 2) * 4))
         return fail("temporary allocation");
@@ -744,7 +785,8 @@ int buildTiles(DevMat* d) {
     // are nearly free (issued under the running stream, served by L2 / Infinity Cache).  Pieces per slice: within the
     // 50-100 k window, minimise  0.35 * idle share of the last round + a tenth of the relative fill traffic.
     uint32_t chunk = PB_CHUNK;
-    {
+    if (o.chunk) chunk = o.chunk;
+    else {
         uint64_t nonEmpty = 0;
         for (uint32_t s = 0; s < t->S; ++s) nonEmpty += sliceStart[s + 1] > sliceStart[s];
         const double avgLen = nonEmpty ? (double)nnz / (double)nonEmpty : 1.0;
@@ -808,25 +850,37 @@ int buildTiles(DevMat* d) {
     PB_TRY(hipMemcpy(t->work, work.data(), work.size() * sizeof(uint3), hipMemcpyHostToDevice));
     PB_TRY(hipDeviceSynchronize());
 
-    static bool attrSet = false;
-    if (!attrSet) {
-        PB_TRY(hipFuncSetAttribute((const void*)pb_expand_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, PB_C * 8));
-        PB_TRY(hipFuncSetAttribute((const void*)pb_expand_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, PB_C * 8));
-        PB_TRY(hipFuncSetAttribute((const void*)pb_reduce_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, PB_R_MAX * 8));
-        PB_TRY(hipFuncSetAttribute((const void*)pb_reduce_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, PB_R_MAX * 8));
-        PB_TRY(hipFuncSetAttribute((const void*)pb_reduce_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, PB_R_MAX * 8));
-        attrSet = true;
-    }
+    // (set at every build: the attribute belongs to the current device, and a process may drive several)
+    PB_TRY(hipFuncSetAttribute((const void*)pb_expand_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, PB_C * 8));
+    PB_TRY(hipFuncSetAttribute((const void*)pb_expand_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, PB_C * 8));
+    PB_TRY(hipFuncSetAttribute((const void*)pb_reduce_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, PB_R_MAX * 8));
+    PB_TRY(hipFuncSetAttribute((const void*)pb_reduce_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, PB_R_MAX * 8));
+    PB_TRY(hipFuncSetAttribute((const void*)pb_reduce_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, PB_R_MAX * 8));
     // products that fit the Infinity Cache (with room for x and the streams) are stored with the default policy so
     // that phase 2 finds them there; larger streams bypass it (microbench_mall.hip: resident 7.0 vs 5.8 TB/s with
     // non-temporal stores; non-resident 4.9 vs 5.1-5.4)
-    t->ntStore = nnz * 8 > PB_RESIDENT_BYTES;
+    t->ntStore = o.ntStore >= 0 ? o.ntStore != 0 : nnz * 8 > PB_RESIDENT_BYTES;
     if (const char* e = getenv("SPMV_PB_NTSTORE")) t->ntStore = atoi(e) != 0;                         // tuning only
+    t->chunk = chunk;
+    PB_TRY(hipEventRecord(ev1, nullptr));
+    PB_TRY(hipEventSynchronize(ev1));
+    float ms = 0;
+    (void)hipEventElapsedTime(&ms, ev0, ev1);
+    t->buildMs = ms;
     d->tiles = t;
+    t = nullptr;                                    // the guard lets go
     return EXIT_SUCCESS;
 }
 
 size_t tilesBytes(const DevMat* d) { return d->tiles ? d->tiles->bytes : 0; }
+
+void tilesInfo(const DevMat* d, spmvTilesInfo* out) {
+    memset(out, 0, sizeof *out);
+    const TileFormat* t = d->tiles;
+    if (!t) return;
+    out->nBins = t->B; out->rowsPerBin = t->R; out->nSlices = t->S; out->taper = t->bins.n1 != 0; out->ntStore = t->ntStore;
+    out->chunk = t->chunk; out->buildMs = t->buildMs; out->bytes = t->bytes;
+}
 
 void tilesShape(const DevMat* d, uint32_t* bins, uint32_t* rowsPerBin) {
     *bins = d->tiles ? d->tiles->B : 0;
@@ -838,7 +892,7 @@ int enqueueTilesExpand(DevMat* d, const double* x, hipStream_t stream) {
     TileFormat* t = d->tiles;
     if (!t) return EXIT_FAILURE;
     double* prod = prodWorkspace(t->nnz, true);      // grows (after a device synchronise) only if it was released meanwhile
-    if (!prod) return EXIT_FAILURE;
+    if (!prod || prodHandover(stream)) return EXIT_FAILURE;
     if (t->nWork) {
         if (t->ntStore)
             hipLaunchKernelGGL(pb_expand_kernel<true>, grid2d(t->nWork, PB_THREADS), dim3(PB_THREADS), PB_C * 8, stream, t->work, t->val,
@@ -858,7 +912,7 @@ int enqueueTilesReduce(DevMat* d, uint32_t binBegin, uint32_t binEnd, double* y,
     if (binBegin == binEnd) return EXIT_SUCCESS;
     const dim3 grid = grid2d((uint64_t)((binEnd - binBegin + 7) / 8) * 8, PB_THREADS);
     const double* prod = prodWorkspace(t->nnz, false);
-    if (!prod) return EXIT_FAILURE;
+    if (!prod || prodHandover(stream)) return EXIT_FAILURE;
     TileDst dst{};
     dst.n = (uint32_t)nExtra;
     for (int i = 0; i < nExtra; ++i) dst.p[i] = extra[i];
@@ -880,7 +934,7 @@ int enqueueTilesReducePush(DevMat* d, double* y, int nExtra, double* const* extr
     TileFormat* t = d->tiles;
     if (!t || nExtra < 1 || nExtra > SPMV_MAX_PEERS) return EXIT_FAILURE;
     const double* prod = prodWorkspace(t->nnz, true);
-    if (!prod) return EXIT_FAILURE;
+    if (!prod || prodHandover(stream)) return EXIT_FAILURE;
     if (!t->ready) {
         if (hipMalloc(&t->ready, ((size_t)t->B + 1) * 4) != hipSuccess) return EXIT_FAILURE;
         if (hipMemset(t->ready, 0, ((size_t)t->B + 1) * 4) != hipSuccess) return EXIT_FAILURE;   // [B] doubles as the failure word

@@ -52,6 +52,8 @@ spmat* ellTranspose(spmat* m) {
     out->N = rows;
     out->MAX_ROW_NZ = rows;
     out->dev = SPMAT_TAG_ELL_TRANSPOSED;
+    out->pitchJA = m->N;        /* the reference's field swap loses the column count: kept here (host structs do not use the
+                                   pitch fields) so that the upload can check column ids against it */
     /* blocked to keep both sides of the transposition in cache */
     enum { TB = 32 };
     for (ulong r0 = 0; r0 < rows; r0 += TB)

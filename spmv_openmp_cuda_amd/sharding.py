@@ -17,6 +17,7 @@ blocks are padded to the largest one; the kernel writes straight into the
 rank's slot of the group's padded buffer, the gather is in place, and the
 blocks are then copied back to back into y (skipped when nothing is padded).
 """
+import time
 from dataclasses import dataclass
 
 import numpy as np
@@ -293,3 +294,129 @@ class PushSpMV:
             lib.spmvHipEventRecord(ev[1])
         if rc:
             raise RuntimeError(self.launcher + " failed")
+
+
+# ---------------------------------------------------------------------------------------------------------
+# Choosing the exchange at start-up.  How y reaches the other ranks is MEASURED (whole steps, slowest rank), not
+# assumed; this is the collective control flow of that search, kept free of anything GPU-specific so that the
+# world_size-2/3 gloo tests drive exactly the code bench.py runs on RCCL.
+@dataclass(frozen=True)
+class ExchangeKey:
+    """A candidate, named by rank-INDEPENDENT parameters only (what a rank derives from its own rows -- its number of
+    bins, the pieces that fit them -- never enters the name: every rank must walk the same list in the same order)."""
+    mode: str               # "rccl" | "push" | "fused" | "pushk"
+    pieces: int = 1         # push: pieces of phase 2 whose rows are pushed while the next piece is reduced
+    groups: int = 1         # row groups per rank (rows of one group travel while the next group is computed)
+    rdiv: int = 1           # two-phase format with bins of 1/rdiv the automatic height
+    taper: bool = False     # two-phase format with tapered bins
+
+    @property
+    def name(self):
+        base = {"rccl": "rccl", "push": f"push-p{self.pieces}", "fused": "fused", "pushk": "pushk"}[self.mode]
+        return base + (f"-g{self.groups}" if self.groups > 1 or self.mode == "rccl" else "") + \
+            (f"-r{self.rdiv}" if self.rdiv > 1 else "") + ("-t" if self.taper else "")
+
+    @property
+    def format_key(self):
+        """which copy of the rank's matrices (row groups, bin layout) the candidate runs on"""
+        return (self.groups, self.rdiv, self.taper)
+
+
+def default_candidates(world, tiles, rccl=True, windows=True, extra=False):
+    """Safest first: RCCL all-gather (the portable collective), then copy-engine pushes into peer windows, then stores
+    issued by the kernels themselves.  At most eight by default; `extra` appends the forms that only make sense once
+    a first hardware run has shown which family wins (more groups / pieces, smaller or tapered bins, push kernel)."""
+    K = ExchangeKey
+    out = []
+    if rccl:
+        out += [K("rccl", groups=1), K("rccl", groups=2)]
+    if windows:
+        out += [K("push", 1)]
+        if tiles:
+            out += [K("push", 4)]
+        out += [K("push", 1, groups=2)]
+        if tiles:
+            out += [K("fused"), K("fused", groups=2)]
+    if extra:
+        if rccl:
+            out += [K("rccl", groups=4)]
+        if windows:
+            out += [K("push", 1, groups=4)]
+            if tiles:
+                out += [K("push", 2), K("push", 8), K("push", 2, groups=2), K("push", 4, taper=True), K("push", 4, groups=2, taper=True),
+                        K("pushk"), K("pushk", groups=2), K("fused", rdiv=2), K("fused", rdiv=4), K("fused", groups=2, rdiv=2),
+                        K("fused", taper=True), K("fused", groups=2, taper=True)]
+    return out
+
+
+def search_exchange(keys, make, dist, torch, device, validate, budget_s=60.0, steps=3, log=lambda *a: None,
+                    on_resolved=lambda i, best_key: None, clock=time.perf_counter):
+    """Collective.  For every key in order: stop when the slowest rank has spent `budget_s` in the search; build the
+    candidate (`make(key)`; an exception on ANY rank drops it on ALL); one validating step behind a poison of y and a
+    barrier (peers write into this rank's y: nobody steps before everybody has poisoned) checked by
+    `validate(cand, ref_y_or_None)` on every rank (a failure on ANY rank drops it on ALL; the first candidate that
+    passes provides the reference y the later ones are compared with element by element); then `steps` timed steps,
+    slowest rank.  Kernel-issued stores ("fused", "pushk") are only tried after a copy-engine push through the same
+    mappings has delivered a correct y.  Every decision is taken on a reduced value, so all ranks take the same
+    branch.  Returns (best candidate or None, report)."""
+    t_start = clock()
+    times, rejected, skipped = {}, {}, {}
+    best, best_key, ref = None, None, None
+
+    def agree(value, op):
+        t = torch.tensor([float(value)], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=op)
+        return float(t[0])
+
+    for i, key in enumerate(keys):
+        if agree(clock() - t_start, dist.ReduceOp.MAX) >= budget_s and best is not None:
+            for k in keys[i:]:
+                skipped[k.name] = "search budget spent"
+            break
+        if key.mode in ("fused", "pushk") and not any(k.mode == "push" and k.name in times for k in keys):
+            skipped[key.name] = "no copy-engine push through the peer windows has delivered a correct y"
+            on_resolved(i, best_key)
+            continue
+        cand = None
+        try:
+            cand = make(key)
+        except Exception as e:                      # noqa: BLE001 -- e.g. out of memory for one more copy of the format
+            log(f"exchange candidate {key.name} could not be set up here: {e}")
+        if agree(1.0 if cand is not None else 0.0, dist.ReduceOp.MIN) == 0.0:
+            rejected[key.name] = "set-up failed on some rank"
+            if cand is not None:
+                cand.free()
+            on_resolved(i, best_key)
+            continue
+        cand.poison()
+        dist.barrier()
+        good = False
+        try:
+            cand.step()
+            good = bool(validate(cand, ref))
+        except Exception as e:                      # noqa: BLE001
+            log(f"exchange candidate {key.name} failed its validating step here: {e}")
+        if agree(1.0 if good else 0.0, dist.ReduceOp.MIN) == 0.0:
+            rejected[key.name] = "y incomplete or different on some rank"
+            cand.free()
+            on_resolved(i, best_key)
+            continue
+        if ref is None:
+            ref = cand.y.clone()
+        dist.barrier()
+        t0 = clock()
+        for _ in range(steps):
+            cand.step()
+        if hasattr(cand, "sync"):
+            cand.sync()
+        times[key.name] = agree((clock() - t0) / steps * 1e3, dist.ReduceOp.MAX)
+        if best is None or times[key.name] < times[best_key.name]:
+            if best is not None:
+                best.free()
+            best, best_key = cand, key
+        else:
+            cand.free()
+        on_resolved(i, best_key)
+    report = {"exchange_step_ms": times, "exchange_rejected": rejected, "exchange_skipped": skipped,
+              "exchange_search_s": agree(clock() - t_start, dist.ReduceOp.MAX), "chosen": best_key.name if best_key else None}
+    return best, report

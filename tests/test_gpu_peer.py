@@ -100,7 +100,7 @@ def test_push_exchange_shared_gpu(tmp_path, world):
 
 
 def test_tapered_bins_single_process():
-    """tapered format (low bins in the first and last round, spmvHipSetTilesTaper): same y, consistent bin -> row map"""
+    """tapered format (low bins in the first and last round, spmvTilesOpts.taper): same y, consistent bin -> row map"""
     import ctypes as C
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from conftest import Oracle
@@ -117,13 +117,12 @@ def test_tapered_bins_single_process():
     y_ref = oracle.csr_serial_dev(irp.astype(np.uint32), ja, as_, x_host)
     scale = np.add.reduceat(np.abs(as_ * x_host[ja]), irp[:-1].astype(np.int64))
     dx = api.DeviceVector(w.N).up(x_host)
-    assert api.lib.spmvHipSetTilesTaper(1) == 0
-    try:
-        dm = synth.device_csr(w, irp, 0, w.N)
-        nb, rpb = C.c_uint(), C.c_uint()
-        assert api.lib.spmvHipTilesShape(C.byref(dm.handle), C.byref(nb), C.byref(rpb)) == 0
-    finally:
-        api.lib.spmvHipSetTilesTaper(0)
+    dm = synth.device_csr(w, irp, 0, w.N)
+    api.build_tiles(dm, taper=True)
+    nb, rpb = C.c_uint(), C.c_uint()
+    assert api.lib.spmvHipTilesShape(C.byref(dm.handle), C.byref(nb), C.byref(rpb)) == 0
+    info = api.tiles_info(dm)
+    assert info.taper == 1 and info.nBins == nb.value and info.buildMs > 0
     rows = []
     for b in range(nb.value + 1):
         r = C.c_ulong()

@@ -81,3 +81,115 @@ def test_bin_ranges_cover_and_align():
         assert all(a[1] == b[0] for a, b in zip(r, r[1:]))
         assert all((b - a) % unit == 0 for a, b in r[:-1]) and all(b > a for a, b in r)
     assert bin_ranges(610, 3, 256) == [(0, 256), (256, 512), (512, 610)]
+
+
+class _CpuExchange:
+    """a candidate of search_exchange on CPU: the oracle computes this rank's rows, gloo gathers them"""
+
+    def __init__(self, key, plan, rank, irp, w, x, oracle, sharding, corrupt=False):
+        import torch as T
+        self.key, self.plan, self.rank, self.irp, self.w, self.x, self.oracle, self.sharding = key, plan, rank, irp, w, x, oracle, sharding
+        self.bufs = sharding.GatherBuffers(plan, rank, T, "cpu")
+        self.y = self.bufs.y
+        self.corrupt = corrupt
+        self.freed = False
+
+    def poison(self):
+        for b in self.bufs.ypad:
+            b.fill_(float("nan"))
+        self.bufs.y.fill_(float("nan"))
+
+    def step(self):
+        from spmv_openmp_cuda_amd import synth
+
+        def compute_group(g, slot):
+            b0, b1 = self.plan.block(self.rank, g)
+            ja, as_ = self.oracle.synth_fill(self.w.N, b0, self.irp[b0:b1 + 1], synth.SEED_STRUCT + self.w.cfg, synth.SEED_VAL + self.w.cfg, 0)
+            il = (self.irp[b0:b1 + 1] - self.irp[b0]).astype(np.uint32)
+            y = self.oracle.csr_serial_dev(il, ja, as_, self.x)
+            if self.corrupt and b1 > b0:
+                y[0] += 1.0
+            slot[: b1 - b0].copy_(torch.from_numpy(y))
+        self.sharding.step(self.plan, dist, self.bufs, compute_group)
+        return self.y
+
+    def free(self):
+        self.freed = True
+
+
+def _search_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from conftest import Oracle
+    from spmv_openmp_cuda_amd import sharding, synth
+    oracle = Oracle()
+    w = synth.Workload("p", 5003, 90000, "powerlaw", 3000, 9)          # 5003 rows: no (world x groups) divides them
+    irp = synth.prefix(synth.row_lengths(w))
+    x = synth.make_x(w.N, w.cfg)
+    ja_all, as_all = oracle.synth_fill(w.N, 0, irp, synth.SEED_STRUCT + w.cfg, synth.SEED_VAL + w.cfg, 0)
+    y_ref = oracle.csr_serial_dev(irp.astype(np.uint32), ja_all, as_all, x)
+    K = sharding.ExchangeKey
+    keys = [K("rccl", groups=1), K("rccl", groups=3), K("push", 1), K("fused"), K("rccl", groups=2), K("rccl", groups=4)]
+    made = []
+
+    def make(key):
+        if key.mode == "push":
+            if rank == world - 1:
+                raise RuntimeError("no peer windows on this rank")        # set-up fails on ONE rank
+            cand = _CpuExchange(key, sharding.make_plan(irp, world, 1), rank, irp, w, x, oracle, sharding)
+        else:
+            # groups = 2: a wrong y on rank 0 only
+            cand = _CpuExchange(key, sharding.make_plan(irp, world, key.groups), rank, irp, w, x, oracle, sharding,
+                                corrupt=(key.groups == 2 and rank == 0))
+        made.append(cand)
+        return cand
+
+    def validate(cand, ref):
+        y = cand.y.numpy()
+        if np.isnan(y).any():
+            return False
+        return np.array_equal(y, y_ref) if ref is None else bool(torch.equal(cand.y, ref))
+
+    resolved = []
+    best, rep = sharding.search_exchange(keys, make, dist, torch, "cpu", validate, budget_s=1e9, steps=2,
+                                         on_resolved=lambda i, bk: resolved.append((i, bk.name if bk else None)))
+    ok = best is not None and not best.freed and rep["chosen"] in ("rccl-g1", "rccl-g3", "rccl-g4")
+    ok = ok and set(rep["exchange_step_ms"]) == {"rccl-g1", "rccl-g3", "rccl-g4"}
+    ok = ok and rep["exchange_rejected"] == {"push-p1": "set-up failed on some rank", "rccl-g2": "y incomplete or different on some rank"}
+    ok = ok and list(rep["exchange_skipped"]) == ["fused"]             # no push candidate was validated
+    ok = ok and [i for i, _ in resolved] == list(range(len(keys)))
+    ok = ok and all(c.freed for c in made if c is not best)
+    ok = ok and np.array_equal(best.step().numpy(), y_ref)
+    # an exhausted budget stops the search behind the first candidate that delivered, on every rank alike
+    best2, rep2 = sharding.search_exchange(keys, make, dist, torch, "cpu", validate, budget_s=0.0, steps=1)
+    ok = ok and rep2["chosen"] == "rccl-g1" and list(rep2["exchange_step_ms"]) == ["rccl-g1"] and len(rep2["exchange_skipped"]) == len(keys) - 1
+    with open(os.path.join(out_dir, f"rank{rank}.txt"), "w") as f:
+        f.write("ok" if ok else f"mismatch {rep} {rep2} {resolved}")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_exchange_search_takes_the_same_branch_on_every_rank(tmp_path, world):
+    """bench.py's start-up search over exchange candidates (sharding.search_exchange) on gloo, with a plan whose row
+    count no (world x groups) divides: a candidate that cannot be built on ONE rank and one whose y is wrong on ONE rank
+    are dropped on ALL ranks, kernel-issued stores are skipped while no push candidate has delivered, losers are freed,
+    and an exhausted budget ends the search on every rank at the same candidate."""
+    port = _free_port()
+    mp.spawn(_search_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    for r in range(world):
+        assert (tmp_path / f"rank{r}.txt").read_text() == "ok"
+
+
+def test_exchange_keys_are_rank_independent():
+    sys.path.insert(0, ROOT)
+    from spmv_openmp_cuda_amd.sharding import default_candidates
+    for tiles in (True, False):
+        d = default_candidates(8, tiles)
+        assert len(d) <= 8 and len({k.name for k in d}) == len(d)
+        assert [k.name for k in d][:3] == ["rccl-g1", "rccl-g2", "push-p1"]                  # safest first
+        e = default_candidates(8, tiles, extra=True)
+        assert e[:len(d)] == d and len({k.name for k in e}) == len(e)
+    assert not any(k.mode in ("fused", "pushk") for k in default_candidates(8, False, extra=True))
