@@ -249,3 +249,23 @@ int oracleMaxThreads(void) { return omp_get_max_threads(); }
 void oracleSetSchedule(int kind, int chunk) { omp_set_schedule((omp_sched_t)kind, chunk); }
 size_t oracleSizeofSpmat(void) { return sizeof(spmat); }
 size_t oracleSizeofConfig(void) { return sizeof(CONFIG); }
+
+/* ---- CPU-baseline helpers (bench.py's cpu_baseline leg only) -------------------------------------------
+ * First touch.  The reference allocates and fills its matrix from ONE thread (malloc + serial fill in
+ * src/lib/parser.c:318-326), so on a NUMA host every page of AS/JA sits on the loading thread's node.
+ * SURVEY 8d asks for both figures: as the reference does it, and with the pages first touched by the threads
+ * that will read them.  oracleFirstTouchCsr copies a CSR into freshly allocated (still untouched) arrays inside
+ * the same static row partition spmvRowsBasicCSR runs with under OMP_SCHEDULE=static. */
+void oracleFirstTouchCsr(ulong M, const ulong* IRP, const ulong* jaSrc, const double* asSrc,
+                         ulong* irpDst, ulong* jaDst, double* asDst, double* y) {
+    #pragma omp parallel for schedule(static)
+    for (ulong r = 0; r < M; r++) {
+        irpDst[r] = IRP[r];
+        for (ulong j = IRP[r]; j < IRP[r + 1]; j++) { jaDst[j] = jaSrc[j]; asDst[j] = asSrc[j]; }
+        y[r] = 0.0;
+    }
+    irpDst[M] = IRP[M];
+}
+/* what libgomp actually bound: number of places and the binding policy (0 false, 1 true, 2 master, 3 close, 4 spread) */
+int oracleOmpPlaces(void) { return omp_get_num_places(); }
+int oracleOmpProcBind(void) { return (int)omp_get_proc_bind(); }

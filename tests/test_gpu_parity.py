@@ -536,10 +536,8 @@ def test_upload_rejects_decreasing_row_pointers_and_bad_transposed_columns(api):
     M, N, IRP, JA, AS = CASES["cage4-shaped"]
     bad = IRP.copy()
     bad[3] = bad[4] + 7                                   # decreases at row 3 -> 4, ends still consistent
-    h = api.HostCSR(M, N, IRP, JA, AS)
-    h.IRP[:] = bad
     with pytest.raises(api.SpmvHipError):
-        api.spMatCpyCSR(h)
+        api.spMatCpyCSR(api.HostCSR(M, N, bad, JA, AS))
     ell_t = api.HostCSR(M, N, IRP, JA, AS).to_ell().transpose()
     ell_t.JA[0, 0] = N + 3                                # column outside the matrix, in the transposed layout
     with pytest.raises(api.SpmvHipError):

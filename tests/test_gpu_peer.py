@@ -215,25 +215,32 @@ def test_tiles_reduce_bin_ranges_single_process():
     dm.free()
 
 
-@pytest.mark.parametrize("world,launcher", [(2, "hipSpMVTilesCSR"), (3, "hipSpMVWarpPerRowCSR")])
-def test_bench_multirank_path_on_shared_gpu(world, launcher):
-    """bench.py's N > 1 code end to end (plan, kernel pick + broadcast, exchange candidates through peer windows,
-    cross-rank and oracle checks, the ONE JSON line) with `world` ranks sharing the GPU; timings mean nothing."""
+@pytest.mark.parametrize("world,launcher,extra", [(2, "hipSpMVTilesCSR", True), (3, "hipSpMVWarpPerRowCSR", False), (2, "hipSpMVTilesCSR", False)])
+def test_bench_multirank_path_on_shared_gpu(world, launcher, extra):
+    """bench.py's N > 1 code end to end (plan, kernel pick + broadcast, exchange search through peer windows, cross-rank
+    byte comparison, oracle windows on every rank, the serial-order validating step, the ONE JSON line) with `world`
+    ranks sharing the GPU; timings mean nothing.  Default list: at most eight candidates, safest first; --exchange-extra
+    adds the other families."""
     import json
     import subprocess
     port = _free_port()
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--rehearse-shared-gpu",
-           "--workload", "c3", "--scale", "0.05", "--steps", "3", "--warmup", "1", "--launcher", launcher]
-    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+           "--workload", "c3", "--scale", "0.05", "--steps", "3", "--warmup", "1", "--launcher", launcher] + (["--exchange-extra"] if extra else [])
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.strip()]
     assert len(lines) == 1, r.stdout                      # exactly one JSON line on stdout
     j = json.loads(lines[0])
-    assert j["n_gpus"] == world and j["parity"]["ok"] and j["parity"]["all_ranks_hold_identical_y"]
-    assert j["config"]["exchange"] in j["config"]["exchange_step_ms"] and not j["config"]["exchange_rejected"]
-    assert any(k.startswith("push") for k in j["config"]["exchange_step_ms"])
-    if launcher == "hipSpMVTilesCSR":                    # every exchange family ran and delivered a complete y
-        for fam in ("fused", "pushk", "fused-g2", "pushk-g2", "fused-r2", "fused-t", "push-p1-g2"):
-            assert fam in j["config"]["exchange_step_ms"], fam
-        assert any(k.endswith("-t") and k.startswith("push-p") for k in j["config"]["exchange_step_ms"])
+    c, p = j["config"], j["parity"]
+    assert j["n_gpus"] == world and p["ok"] and p["all_ranks_hold_identical_y"] and p["every_rank_matches_oracle_windows"]
+    assert p["serial_order_step"]["all_ranks_hold_identical_bytes"] and p["serial_order_step"]["bit_identical_to_serial_oracle_on_every_rank"]
+    assert c["exchange"] in c["exchange_step_ms"] and not c["exchange_rejected"] and c["exchange_search_s"] > 0
+    assert any(k.startswith("push") for k in c["exchange_step_ms"])
+    if not extra:
+        assert len(c["exchange_step_ms"]) + len(c["exchange_skipped"]) <= 8
+    if launcher == "hipSpMVTilesCSR":
+        assert "fused" in c["exchange_step_ms"] and "fused-g2" in c["exchange_step_ms"] and "push-p4" in c["exchange_step_ms"]
+    if extra:                                             # every exchange family ran and delivered a complete y
+        for fam in ("pushk", "pushk-g2", "fused-r2", "fused-t", "push-p1-g2", "push-p4-t"):
+            assert fam in c["exchange_step_ms"], fam
