@@ -233,6 +233,7 @@ def measure_single(api, synth, torch, w, launcher, steps, warmup, candidates=Non
     res.update({
         "workload": info, "launcher": launcher, "auto_candidates_ms": tried,
         "eligible_launchers": list(candidates) if candidates else "all",
+        "fastest_of_all_launchers": min(tried, key=tried.get) if tried else launcher,
         "kernel_ms_avg": k_avg, "kernel_ms_var": k_var, "kernel_ms_min": min(kms),
         "gflops": 2.0 * nnz / (res["ms_per_step"] * 1e-3) * 1e-9,
         "hbm_gbps": bytes_alg / (k_avg * 1e-3) * 1e-9, "hbm_frac": bytes_alg / (k_avg * 1e-3) / HBM_PEAK,

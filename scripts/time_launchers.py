@@ -39,6 +39,7 @@ def main():
     nnz = int(irp[-1])
     alg = synth.algorithmic_bytes_csr(nnz, w.N, w.N)
     cfg = api.CONFIG()
+    windows = None
     for name in a.launchers:
         fn = api.SPMV_LAUNCHERS[name]
         y.fill_(float("nan"))
@@ -52,8 +53,10 @@ def main():
             api.lib.spmvHipStripesShape(C.byref(dm.handle), C.byref(nb), C.byref(rpb), C.byref(wide), C.byref(ms))
             extra = f" bins={nb.value} rows/bin<={rpb.value} wide={wide.value} build={ms.value:.1f}ms"
         if a.check:
-            spot = bench.oracle_spot_checks(synth, w, irp, x_host, lambda r0, r1: y[r0:r1].cpu().numpy())
-            extra += " check=" + ("ok" if all(not c["nan"] and c["max_abs_diff"] <= 1e-12 for c in spot) else "FAIL " + str(spot))
+            if windows is None:
+                windows = bench.OracleWindows(synth, w, irp, x_host, lens)
+            par = windows.check(lambda r0, r1: y[r0:r1].cpu().numpy())
+            extra += " check=" + ("ok" if par["ok"] and par["max_diff_over_sum_abs_ax"] <= 1e-12 else "FAIL " + str(par))
         for _ in range(3):
             fn(C.byref(dm.handle), x.data_ptr(), cfg, y.data_ptr())
         evs = [(C.c_void_p(), C.c_void_p()) for _ in range(a.steps)]

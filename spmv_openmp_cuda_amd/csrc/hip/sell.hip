@@ -14,6 +14,11 @@
 //   * slice quadruples (one workgroup) are dealt to the 8 XCDs in contiguous ranges: with the default
 //     round-robin placement every XCD's L2 sees every sorting window and thrashes (measured on a
 //     +-512 band, sigma = 16 Ki: 3.8 ms round-robin vs 1.29 ms contiguous);
+//   * (tried and removed, profiles/r02_sell_column_stripes_c2.log: storing the slices per COLUMN STRIPE of 1-4 MiB of x,
+//     one launch per stripe with a lane continuing its row's sum from y, so that every launch gathers from a window of
+//     x that stays in an XCD's L2.  Bit-identical and correct -- and no faster on config 2: 0.232 ms against 0.237.
+//     With one lane per row the 64 lanes of a gather touch 64 different lines whatever cache serves them, and the rate
+//     at which a CU's L1 takes lines from L2 (~0.3 per clock) is the bound, not where the lines come from;)
 //   * rows longer than SELL_MAX_ROW do not enter the slices (one of them would pin a wavefront for
 //     a whole slice): they are processed workgroup-per-row from the CSR arrays (shuffle tree).
 #include <hip/hip_runtime.h>
