@@ -4,28 +4,35 @@
 // from the fabric (x lives beyond L2: <= 56 G gathers/s), and the two-phase kernel
 // (tiles.hip) buys streaming accesses with 16 extra bytes per entry (products out and back).  This kernel
 // keeps ONE pass of 12 B/nnz and moves the gather into L2 instead:
-//   * rows are cut into bins of <= 20 000 consecutive rows with (nearly) equal entry counts; a 1024-thread
-//     workgroup owns a bin and keeps its y in LDS (ds_add_f64);
+//   * rows are cut into bins of <= 20 000 consecutive rows with (nearly) equal entry counts; a workgroup owns a
+//     bin and keeps its y in LDS (ds_add_f64); one workgroup per CU, persistent over the bins w, w + 256, ...;
 //   * inside a bin the entries are stored in COLUMN order.  Every workgroup therefore sweeps x from column 0
-//     to N-1 at the pace of its entry stream; the 32 workgroups resident on one XCD run the same sweep at the
-//     same average pace (equal entry counts), so a line of x fetched by the first of them is found in that
-//     XCD's 4 MiB L2 by the others: the gather is an L2 hit, and the column order lets neighbouring lanes
-//     share lines;
-//   * a step = 128 consecutive entries of a bin (two per lane): fp64 values and one 32-bit word per entry,
-//     {17-bit column offset from the step's first column, 15-bit local row}; the step's first column is a
-//     scalar load.  12.03 B/nnz.  A matrix with a step spanning >= 2^17 columns uses the WIDE encoding
-//     (32-bit column + 16-bit local row, 14 B/nnz) -- same kernel, other template argument.
-// HBM sees the 12 B/nnz stream, x once per round of bins and y once.  What bounds the kernel is the L2
-// request rate (one line per gather that shares its line with no neighbour) and, for very wide matrices, the
-// fabric: every XCD re-reads the lines of x its 32 bins touch in every round of bins, so the format pays off
-// while x (N * 8 B) is small against the entry stream (c3: 80 MB per XCD and round against 2.4 GB).
+//     to N-1 at the pace of its entry stream; the 32 workgroups resident on one XCD run the same sweep at about
+//     the same pace (equal entry counts), so most lines of x are found in that XCD's 4 MiB L2, and the column
+//     order lets neighbouring lanes share lines (a bin of R rows holds R.16.nnz/(M.N) entries per line of x:
+//     0.64 on c3, 2 on c2, ~8 on the +-16 Ki band);
+//   * a step = 128 consecutive entries of a bin, dealt to the lanes as (e, 64 + e): fp64 values and one 32-bit
+//     word per entry, {17-bit column offset from the step's first column, 15-bit local row}; the step's first
+//     column is a scalar load.  12.03 B/nnz.  A matrix with a step spanning >= 2^17 columns uses the WIDE
+//     encoding (32-bit column + 16-bit local row, 14 B/nnz) -- same kernel, other template argument.
+// HBM sees the 12 B/nnz stream, x once per XCD and round of bins and y once.
+//
+// Measured (profiles/r02_summary.md): c2 0.110 ms = 46 % of the 8 TB/s roofline (two-phase 0.149, SELL 0.237);
+// c3 0.88 ms = 37 % (two-phase 1.03); band +-16 Ki 0.41 ms = 78 % (5.9 TB/s of algorithmic bytes).
+// What bounds it when the columns have no locality is the rate at which a CU's L1 takes lines from L2 -- each
+// gather instruction touches ~47 distinct lines on c3, and 0.27-0.38 lines per clock and CU is what this kernel and
+// scripts/microbench_gather.hip both reach (~64 lines in flight per CU over ~200 clocks) -- not HBM, and not L2
+// misses: see the throttle note below.  For very wide matrices the fabric takes over: every XCD re-reads the lines
+// of x its 32 bins touch in every round of bins (c5: 0.08 entries per line and bin -> 50 B of line fills per
+// entry), so the format pays off while x (N * 8 B) is small against the entry stream -- bench.py tries it while x
+// fits the Infinity Cache; wider matrices are the two-phase kernel's.
 //
 // Relation to the reference: the computation of cudaSpMVWarpPerRowCSR (src/SpMV_CUDA.cu:52-73) -- lanes
 // multiply entries of coalesced AS/JA spans with gathered x and the partial sums are reduced on chip -- with
 // the reduction moved from a shuffle tree per row to LDS accumulators per bin of rows, which is what allows
 // the column order.  Sums are added in arrival order: equal to the serial oracle to rounding, not bitwise.
 //
-// The format is built ON THE DEVICE from the device CSR (rocPRIM radix sort of (bin, column) keys).
+// The format is built ON THE DEVICE from the device CSR (rocPRIM radix sort of (bin, column) keys; c3: ~60 ms).
 #include <hip/hip_runtime.h>
 #include <cstring>
 #include <rocprim/device/device_radix_sort.hpp>
@@ -39,7 +46,7 @@ namespace spmvhip {
 
 constexpr uint32_t SB_R_MAX   = 20000;              // rows per bin: <= 156.25 KiB of y in LDS
 #ifndef SPMV_SB_THREADS
-#define SPMV_SB_THREADS 512
+#define SPMV_SB_THREADS 256
 #endif
 constexpr int      SB_THREADS = SPMV_SB_THREADS;
 constexpr uint32_t SB_WAVES   = SB_THREADS / 64;
@@ -48,7 +55,7 @@ constexpr uint32_t SB_ROWBITS = 15;
 constexpr uint32_t SB_NONE    = (1u << SB_ROWBITS) - 1;     // local row of a padding entry (SB_R_MAX < SB_NONE)
 constexpr uint32_t SB_DCOL_LIMIT = 1u << (32 - SB_ROWBITS);
 #ifndef SPMV_SB_DEPTH
-#define SPMV_SB_DEPTH 4
+#define SPMV_SB_DEPTH 6
 #endif
 constexpr int      SB_DEPTH   = SPMV_SB_DEPTH;      // steps per register batch
 constexpr uint32_t SB_CUS     = 256;
@@ -170,8 +177,13 @@ __device__ __forceinline__ void sb_stream(SbStream& s, uint32_t t, uint32_t s0, 
     for (int u = 0; u < SB_DEPTH; ++u) {
         const uint32_t sc = min(s.first + u, s1 - 1u);
         const uint64_t q = (uint64_t)sc * SB_STEP + 2u * lane;
+#ifdef SPMV_SB_STREAM_PLAIN     // tuning: default cache policy for the entry stream
+        s.v[u] = *(const dbl2*)(val + q);
+        s.c[u] = *(const u32x2*)(cr + q);
+#else
         s.v[u] = __builtin_nontemporal_load((const dbl2*)(val + q));
         s.c[u] = __builtin_nontemporal_load((const u32x2*)(cr + q));
+#endif
         if (WIDE) { s.r[u] = __builtin_nontemporal_load((const u16x2*)(lrowW + q)); s.base[u] = 0; }
         else      { s.base[u] = stepBase[sc]; s.r[u] = u16x2{0, 0}; }
     }
