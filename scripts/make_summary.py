@@ -1,19 +1,27 @@
 #!/usr/bin/env python3
-"""gpurun_out/r01c (written by scripts/final_profile.sh on the GPU box) -> profiles/r01_summary.md + profiles/traffic.json"""
-import collections, csv, glob, json
-O = 'gpurun_out/r01c'
+"""gpurun_out/<round>c (written by scripts/final_profile.sh on the GPU box) -> profiles/<round>_summary.md,
+profiles/<round>_default_bench_kernel_stats.csv, profiles/<round>_bench_default.json and profiles/traffic.json
+(stamped with the sha256 of the library that was profiled: bench.py reports a traffic figure only for that build).
+    usage: python3 scripts/make_summary.py r02"""
+import collections, csv, glob, json, os, shutil, sys
+RND = sys.argv[1] if len(sys.argv) > 1 else "r02"
+O = f"gpurun_out/{RND}c"
 def short(n): return n.replace("void ", "").replace("spmvhip::", "").replace("(anonymous namespace)::", "").split("(")[0]
-lines = ["# r01 profile summary (rocprofv3, one MI355X) -- `scripts/final_profile.sh` + `scripts/make_summary.py`", "",
+sha = open(f"{O}/libspmvhip.sha256").read().strip()
+lines = [f"# {RND} profile summary (rocprofv3, one MI355X) -- `scripts/final_profile.sh {RND}` + `scripts/make_summary.py {RND}`", "",
+         f"Library profiled: `libspmvhip.so` sha256 `{sha}`.", "",
          "Per workload: `rocprofv3 --kernel-trace --stats` durations and, from separate `--pmc` passes, HBM-side traffic",
          "per launch = 2 x FETCH_SIZE KiB + WRITE_SIZE KiB (gfx950 correction of MI355X_MICROARCH.md: a 128-B fabric read is",
          "tallied as 64 B).  Algorithmic bytes: nnz*12 + M*12 + N*8.", ""]
-traffic = {"_doc": "HBM-side bytes per SpMV from rocprofv3 PMC passes (2 x FETCH_SIZE KiB + WRITE_SIZE KiB); bench.py copies the entry "
-                   "matching workload+kernel into roofline.traffic; source profiles/r01_summary.md"}
-wlname = {"c5": "c5-powerlaw-80M-1.6G", "c3": "c3-powerlaw-10M-200M", "c3_onepass": "c3-powerlaw-10M-200M",
-          "c3n": "c3n-powerlaw-10M-200M-band512", "c2": "c2-uniform-1M-32"}
-alg = {"c5": 20.8e9, "c3": 2.6e9, "c3_onepass": 2.6e9, "c3n": 2.6e9, "c2": 0.404e9}
-KEEP = ("csr_stream", "pb_expand", "pb_reduce", "csr_scalar", "csr_vector", "sell_spmv", "sell_long")
-for tag in ("c5", "c3", "c3_onepass", "c3n", "c2"):
+traffic = {"_doc": "HBM-side bytes per SpMV from rocprofv3 PMC passes (2 x FETCH_SIZE KiB + WRITE_SIZE KiB); bench.py copies the entry matching "
+                   f"workload+kernel into roofline.traffic when the loaded library has this sha256; source profiles/{RND}_summary.md",
+           "_libspmvhip_sha256": sha, "_measured": f"profiles/{RND}_summary.md"}
+wlname = {"c5": "c5-powerlaw-80M-1.6G", "c3": "c3-powerlaw-10M-200M", "c3_tiles": "c3-powerlaw-10M-200M", "c3_onepass": "c3-powerlaw-10M-200M",
+          "c2_stripes": "c2-uniform-1M-32", "c2_sell": "c2-uniform-1M-32", "c3b": "c3b-powerlaw-10M-200M-band"}
+alg = {"c5": 20.8e9, "c3": 2.6e9, "c3_tiles": 2.6e9, "c3_onepass": 2.6e9, "c2_stripes": 0.404e9, "c2_sell": 0.404e9, "c3b": 2.6e9}
+KEEP = ("csr_stream", "pb_expand", "pb_reduce", "csr_scalar", "csr_vector", "sell_spmv", "sell_long", "sb_spmv")
+LAUNCHER = (("pb_", "hipSpMVTilesCSR"), ("sb_spmv", "hipSpMVStripesCSR"), ("sell", "hipSpMVRowsSELL"), ("csr_stream", "hipSpMVWarpPerRowCSR"))
+for tag in wlname:
     tr = collections.defaultdict(list)
     for p in glob.glob(f"{O}/{tag}/trace/*/*_kernel_trace.csv"):
         for r in csv.DictReader(open(p)):
@@ -33,22 +41,26 @@ for tag in ("c5", "c3", "c3_onepass", "c3n", "c2"):
     used = []
     for k, d in sorted(tr.items(), key=lambda kv: -len(kv[1])):
         if len(d) < maxcalls * 0.6: continue
+        d = sorted(d)[: max(1, len(d) - 3)] if "sb_spmv" in k or "pb_" in k else d      # first calls of a format-building launcher are not slower, but drop warm-up outliers
         a = {n: sum(v) / len(v) for n, v in pm[k].items()}
         rd, wr = a.get("FETCH_SIZE", 0) * 2048, a.get("WRITE_SIZE", 0) * 1024
         hit = a.get("TCC_HIT_sum", 0) / max(a.get("TCC_HIT_sum", 0) + a.get("TCC_MISS_sum", 0), 1)
-        wc = a.get("SQ_WAVE_CYCLES", 1)
-        lines.append(f"| {k} | {len(d)} | {sum(d) / len(d) / 1e3:.1f} | {min(d) / 1e3:.1f} | {rd / 1e9:.2f} | {wr / 1e9:.2f} | {hit:.2f} | "
-                     f"{a.get('SQ_WAIT_ANY', 0) / wc:.2f} / {a.get('SQ_WAIT_INST_ANY', 0) / wc:.2f} / {a.get('SQ_ACTIVE_INST_ANY', 0) / wc:.2f} |")
+        wc = a.get("SQ_WAVE_CYCLES", 0)
+        sq = f"{a.get('SQ_WAIT_ANY', 0) / wc:.2f} / {a.get('SQ_WAIT_INST_ANY', 0) / wc:.2f} / {a.get('SQ_ACTIVE_INST_ANY', 0) / wc:.2f}" if wc else "-"
+        lines.append(f"| {k} | {len(d)} | {sum(d) / len(d) / 1e3:.1f} | {min(d) / 1e3:.1f} | {rd / 1e9:.2f} | {wr / 1e9:.2f} | {hit:.2f} | {sq} |")
         tot += rd + wr; tott += sum(d) / len(d); used.append(k)
     lines += ["", f"SpMV = {tott / 1e3:.1f} us, HBM-side traffic {tot / 1e9:.2f} GB = {tot / alg[tag]:.2f} x algorithmic; algorithmic rate "
                   f"{alg[tag] / tott:.0f} GB/s = {100 * alg[tag] / tott / 8000:.1f} % of 8 TB/s", ""]
-    launcher = ("hipSpMVTilesCSR" if any("pb_" in k for k in used) else "hipSpMVRowsSELL" if any("sell" in k for k in used)
-                else "hipSpMVRowsCSR" if tag == "c2" else "hipSpMVWarpPerRowCSR")
-    traffic.setdefault(wlname[tag], {})[launcher] = tot
-old = json.load(open("profiles/traffic.json"))
-for wl, d in old.items():                      # keep entries measured in earlier passes (e.g. the one-pass kernel on c5)
-    if wl != "_doc":
-        for k, v in d.items(): traffic.setdefault(wl, {}).setdefault(k, v)
-open("profiles/r01_summary.md", "w").write("\n".join(lines) + "\n")
+    launcher = next(l for key, l in LAUNCHER if any(key in k for k in used))
+    if tot:
+        traffic.setdefault(wlname[tag], {})[launcher] = tot
+os.makedirs("profiles", exist_ok=True)
+open(f"profiles/{RND}_summary.md", "w").write("\n".join(lines) + "\n")
 json.dump(traffic, open("profiles/traffic.json", "w"), indent=1)
+for p in glob.glob(f"{O}/default/trace/*/*_kernel_stats.csv") or glob.glob(f"{O}/c5/trace/*/*_kernel_stats.csv"):
+    shutil.copy(p, f"profiles/{RND}_default_bench_kernel_stats.csv")
+if os.path.exists(f"{O}/default.trace.json"):          # the line the default command printed under the profiler, for the cross-check
+    shutil.copy(f"{O}/default.trace.json", f"profiles/{RND}_default_bench_under_trace.json")
+if os.path.exists(f"{O}/bench_default.json"):
+    shutil.copy(f"{O}/bench_default.json", f"profiles/{RND}_bench_default.json")
 print("\n".join(l for l in lines if l.startswith("SpMV =") or l.startswith("## ")))
