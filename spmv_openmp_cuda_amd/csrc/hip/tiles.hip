@@ -540,19 +540,34 @@ __global__ __launch_bounds__(256) void pb_wavetile_kernel(uint32_t B, const uint
     waveTile[i] = lo | (dupCount[i] * 8 >= len ? P2_RUNS_FLAG : 0u);
 }
 
-// entries that repeat the row of their predecessor in the bin-major order, counted per wavefront range of phase 2
+// entries that repeat the row of their predecessor in the bin-major order, counted per wavefront range of phase 2.
+// The 64 positions of a wavefront fall into one or two of those ranges, so the lanes that share the range of the first
+// counting lane add their count with ONE atomic (a banded matrix repeats the row in 9 entries out of 10: one atomic per
+// entry on a few thousand counters took 166 ms of the format build, profiles/r02_default_bench_kernel_stats.csv).
 __global__ __launch_bounds__(256) void pb_dupcount_kernel(uint32_t B, uint64_t nnz, const uint32_t* __restrict__ binPos,
                                                           const uint16_t* __restrict__ lrow, uint32_t* __restrict__ dupCount) {
     const uint64_t v = lin_block() * 256 + threadIdx.x;
-    if (v == 0 || v >= nnz || lrow[v] != lrow[v - 1]) return;
-    uint32_t lo = 0, hi = B;                        // bin with binPos[bin] <= v < binPos[bin + 1]
-    while (hi - lo > 1) {
-        const uint32_t mid = lo + (hi - lo) / 2;
-        if (binPos[mid] <= v) lo = mid; else hi = mid;
+    bool dup = v != 0 && v < nnz && lrow[v] == lrow[v - 1];
+    uint64_t slot = 0;
+    if (dup) {
+        uint32_t lo = 0, hi = B;                    // bin with binPos[bin] <= v < binPos[bin + 1]
+        while (hi - lo > 1) {
+            const uint32_t mid = lo + (hi - lo) / 2;
+            if (binPos[mid] <= v) lo = mid; else hi = mid;
+        }
+        const uint32_t v0 = binPos[lo], v1 = binPos[lo + 1];
+        if (v == v0) dup = false;                   // the predecessor belongs to another bin
+        else slot = (uint64_t)lo * P2_WAVES + (uint32_t)((v - v0) / p2_sub(v1 - v0));
     }
-    const uint32_t v0 = binPos[lo], v1 = binPos[lo + 1];
-    if (v == v0) return;                            // the predecessor belongs to another bin
-    atomicAdd(&dupCount[(uint64_t)lo * P2_WAVES + (uint32_t)((v - v0) / p2_sub(v1 - v0))], 1u);
+    uint64_t todo = __builtin_amdgcn_ballot_w64(dup);
+    while (todo) {                                  // wavefront-uniform: one round per distinct counter (mostly one)
+        const int leader = __builtin_ctzll(todo);
+        const uint64_t s0 = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(slot >> 32), leader) << 32) |
+                            (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)slot, leader);
+        const uint64_t same = __builtin_amdgcn_ballot_w64(dup && slot == s0);
+        if ((int)(threadIdx.x % 64) == leader) atomicAdd(&dupCount[s0], (uint32_t)__builtin_popcountll(same));
+        todo &= ~same;
+    }
 }
 
 #define PB_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { fprintf(stderr, "libspmvhip: tiles: %s: %s\n", #expr, hipGetErrorString(e_)); return EXIT_FAILURE; } } while (0)

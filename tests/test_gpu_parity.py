@@ -542,3 +542,59 @@ def test_upload_rejects_decreasing_row_pointers_and_bad_transposed_columns(api):
     ell_t.JA[0, 0] = N + 3                                # column outside the matrix, in the transposed layout
     with pytest.raises(api.SpmvHipError):
         api.spMatCpyELL(ell_t)
+
+
+@pytest.mark.parametrize("name", ["irregular", "wide", "banded", "ones"])
+def test_stripes_many_small_bins(api, oracle, name, monkeypatch):
+    """The stripes kernel with bins of at most 64 rows (tuning knob SPMV_SB_ROWS): hundreds of bins on a small matrix,
+    i.e. several bins per persistent workgroup, bins without entries, single-row bins holding a long row."""
+    import ctypes as C
+    monkeypatch.setenv("SPMV_SB_ROWS", "64")
+    M, N, IRP, JA, AS = CASES[name]
+    x = _x(np.random.default_rng(17), N)
+    y_ref = oracle.csr_serial(IRP, JA, AS, x)
+    dmat = api.spMatCpyCSR(api.HostCSR(M, N, IRP, JA, AS))
+    y = _run(api, "hipSpMVStripesCSR", dmat, x, M)
+    nb, rpb = C.c_uint(), C.c_uint()
+    assert api.lib.spmvHipStripesShape(C.byref(dmat.handle), C.byref(nb), C.byref(rpb), None, None) == 0
+    assert rpb.value <= 64 and nb.value >= (M + 63) // 64
+    dmat.free()
+    assert not np.isnan(y).any()
+    assert np.max(np.abs(y - y_ref), initial=0.0) <= GATE
+    assert tight_error(IRP, JA, AS, x, y_ref, y) <= TIGHT
+
+
+def test_tiles_build_options(api, oracle):
+    """spmvHipBuildTilesOpt: options are arguments of the build (no process state), an explicit build replaces the format,
+    out-of-range options are refused, and spmvHipTilesInfo reports what was built."""
+    import ctypes as C
+    M, N, IRP, JA, AS = CASES["wide"]
+    x = _x(np.random.default_rng(19), N)
+    y_ref = oracle.csr_serial(IRP, JA, AS, x)
+    dmat = api.spMatCpyCSR(api.HostCSR(M, N, IRP, JA, AS))
+    assert api.tiles_info(dmat).nBins == 0                       # nothing built yet
+    for rows, chunk, nt in ((0, 0, -1), (128, 4096, 0), (4096, 65536, 1), (0, 0, -1)):
+        api.build_tiles(dmat, rowsPerBin=rows, chunk=chunk, ntStore=nt)
+        info = api.tiles_info(dmat)
+        assert info.nBins >= 1 and info.buildMs > 0 and info.bytes > 0
+        if rows:
+            assert info.rowsPerBin == rows and info.nBins == (M + rows - 1) // rows
+        if chunk:
+            assert info.chunk == chunk
+        if nt >= 0:
+            assert info.ntStore == nt
+        y = _run(api, "hipSpMVTilesCSR", dmat, x, M)
+        assert not np.isnan(y).any() and tight_error(IRP, JA, AS, x, y_ref, y) <= TIGHT
+    for bad in (dict(rowsPerBin=63), dict(rowsPerBin=20001), dict(chunk=100)):
+        with pytest.raises(api.SpmvHipError):
+            api.build_tiles(dmat, **bad)
+    # a second matrix built afterwards is NOT affected by the options of the first (there is no global toggle any more)
+    d2 = api.spMatCpyCSR(api.HostCSR(M, N, IRP, JA, AS))
+    _run(api, "hipSpMVTilesCSR", d2, x, M)
+    auto = api.tiles_info(d2)
+    api.build_tiles(dmat, rowsPerBin=128)
+    d3 = api.spMatCpyCSR(api.HostCSR(M, N, IRP, JA, AS))
+    _run(api, "hipSpMVTilesCSR", d3, x, M)
+    assert api.tiles_info(d3).rowsPerBin == auto.rowsPerBin and api.tiles_info(d3).nBins == auto.nBins
+    for d in (dmat, d2, d3):
+        d.free()
