@@ -74,6 +74,8 @@ def main():
             api.lib.spmvHipEventDestroy(e0)
             api.lib.spmvHipEventDestroy(e1)
         avg = sum(ms) / len(ms)
+        if os.environ.get("SPMV_PRINT_STEPS"):
+            print("steps ms:", " ".join(f"{t:.3f}" for t in ms))
         print(f"{w.name} {name}: avg {avg:.4f} ms  min {min(ms):.4f}  max {max(ms):.4f}  = {alg / avg / 8e9 * 100:.1f}% of 8 TB/s "
               f"({2 * nnz / avg * 1e-6:.0f} GFLOP/s){extra}", flush=True)
     dm.free()

@@ -59,6 +59,10 @@ constexpr uint32_t SB_DCOL_LIMIT = 1u << (32 - SB_ROWBITS);
 #endif
 constexpr int      SB_DEPTH   = SPMV_SB_DEPTH;      // steps per register batch
 constexpr uint32_t SB_CUS     = 256;
+#ifndef SPMV_SB_SPREAD
+#define SPMV_SB_SPREAD 6
+#endif
+constexpr uint32_t SB_SPREAD  = SPMV_SB_SPREAD;     // 1/1024ths of a bin over which the sweeps of one XCD's workgroups start
 constexpr uint64_t SB_MIN_BIN_NNZ = 16384;          // do not cut a small matrix into bins shorter than this
 
 struct StripeFormat {
@@ -167,12 +171,17 @@ __global__ __launch_bounds__(256) void sb_fill16_kernel(uint16_t* __restrict__ p
 struct SbStream { dbl2 v[SB_DEPTH]; u32x2 c[SB_DEPTH]; u16x2 r[SB_DEPTH]; uint32_t base[SB_DEPTH]; uint32_t first; };
 struct SbGather { double x0[SB_DEPTH], x1[SB_DEPTH]; };
 
-// stream loads of the batch with ticket `t` (wavefront-uniform): steps s0 + t * SB_DEPTH + u
+// stream loads of the batch with ticket `t` (wavefront-uniform).  A bin has nb batches of SB_DEPTH steps; ticket t stands
+// for batch (t + off) mod nb -- the workgroup starts its column sweep `off` batches into the bin and wraps around (the
+// order in which a bin's entries are added is free) -- and tickets >= nb for nothing (first = s1: loads clamped, adds skipped).
+struct SbBin { uint32_t s0, s1, nb, off; };
 template <bool WIDE>
-__device__ __forceinline__ void sb_stream(SbStream& s, uint32_t t, uint32_t s0, uint32_t s1, uint32_t lane,
+__device__ __forceinline__ void sb_stream(SbStream& s, uint32_t t, const SbBin bn, uint32_t lane,
                                           const double* __restrict__ val, const uint32_t* __restrict__ cr,
                                           const uint16_t* __restrict__ lrowW, const uint32_t* __restrict__ stepBase) {
-    s.first = s0 + t * SB_DEPTH;
+    const uint32_t s1 = bn.s1;
+    const uint32_t rb = t + bn.off;
+    s.first = t < bn.nb ? bn.s0 + (rb >= bn.nb ? rb - bn.nb : rb) * SB_DEPTH : s1;
 #pragma unroll
     for (int u = 0; u < SB_DEPTH; ++u) {
         const uint32_t sc = min(s.first + u, s1 - 1u);
@@ -192,13 +201,21 @@ __device__ __forceinline__ void sb_stream(SbStream& s, uint32_t t, uint32_t s0, 
 #ifndef SPMV_SB_GATHER
 #define SPMV_SB_GATHER 0
 #endif
-__device__ __forceinline__ double sb_ldx(const double* p) {      // tuning: cache policy of the x gather
-#if SPMV_SB_GATHER == 1
-    return __builtin_nontemporal_load(p);
+__device__ __forceinline__ double sb_ldx(const double* __restrict__ x, uint32_t c) {      // tuning: form / cache policy of the x gather
+#if SPMV_SB_GATHER == 3       // bound probe (scripts/r02_stripes_bounds.sh): no gather at all -- the stream and the LDS adds alone
+    return 1.0 + (double)(c & 8u);
+#elif SPMV_SB_GATHER == 1
+    return __builtin_nontemporal_load(x + c);
 #elif SPMV_SB_GATHER == 2
-    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return __hip_atomic_load(x + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#elif SPMV_SB_GATHER == 4     // buffer_load_dwordx2 with a 32-bit byte offset per lane (x < 4 GiB)
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, 0xFFFFFFFFu, 0x00020000);
+    const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rs, c << 3, 0, 0);
+    return __longlong_as_double(((unsigned long long)v.y << 32) | v.x);
+#elif SPMV_SB_GATHER == 5     // global_load_dwordx2 with a scalar base and a 32-bit byte offset per lane (x < 4 GiB)
+    return *(const double*)((const char*)x + (uint32_t)(c << 3));
 #else
-    return *p;
+    return x[c];
 #endif
 }
 
@@ -208,8 +225,8 @@ __device__ __forceinline__ void sb_gather(SbGather& g, const SbStream& s, const 
     for (int u = 0; u < SB_DEPTH; ++u) {
         const uint32_t c0 = WIDE ? s.c[u].x : s.base[u] + (s.c[u].x >> SB_ROWBITS);
         const uint32_t c1 = WIDE ? s.c[u].y : s.base[u] + (s.c[u].y >> SB_ROWBITS);
-        g.x0[u] = sb_ldx(x + c0);
-        g.x1[u] = sb_ldx(x + c1);
+        g.x0[u] = sb_ldx(x, c0);
+        g.x1[u] = sb_ldx(x, c1);
     }
 }
 
@@ -220,8 +237,15 @@ __device__ __forceinline__ void sb_add(double* yb, const SbStream& s, const SbGa
         const uint32_t r0 = WIDE ? s.r[u].x : s.c[u].x & SB_NONE;
         const uint32_t r1 = WIDE ? s.r[u].y : s.c[u].y & SB_NONE;
         if (s.first + u < s1) {                      // wavefront-uniform
+#ifdef SPMV_SB_NOADD          // bound probe: the stream and the gathers alone (products summed per lane, one LDS add per step)
+            double t = 0.0;
+            if (r0 != SB_NONE) t += s.v[u].x * g.x0[u];
+            if (r1 != SB_NONE) t += s.v[u].y * g.x1[u];
+            if (t == 1.2345e300) atomicAdd(&yb[r0 % 64], t);
+#else
             if (r0 != SB_NONE) atomicAdd(&yb[r0], s.v[u].x * g.x0[u]);
             if (r1 != SB_NONE) atomicAdd(&yb[r1], s.v[u].y * g.x1[u]);
+#endif
         }
     }
 }
@@ -251,7 +275,7 @@ template <bool WIDE>
 __global__ __launch_bounds__(SB_THREADS) void sb_spmv_kernel(
     uint32_t B, const uint32_t* __restrict__ binRow, const uint32_t* __restrict__ binStep,
     const double* __restrict__ val, const uint32_t* __restrict__ cr, const uint16_t* __restrict__ lrowW,
-    const uint32_t* __restrict__ stepBase, const double* __restrict__ x, double* __restrict__ y, uint32_t ldsRows) {
+    const uint32_t* __restrict__ stepBase, const double* __restrict__ x, double* __restrict__ y, uint32_t ldsRows, uint32_t spread) {
     extern __shared__ double yb[];                  // ldsRows doubles (rows of the highest bin), then the ticket counter
     uint32_t* ctr = reinterpret_cast<uint32_t*>(yb + ldsRows);
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x / 64)), lane = threadIdx.x % 64;
@@ -271,10 +295,16 @@ __global__ __launch_bounds__(SB_THREADS) void sb_spmv_kernel(
 #endif
         SbStream a, b, c, d;
         SbGather g0, g1;
+        // where this workgroup starts its sweep: the (up to) 32 workgroups of an XCD -- workgroups are dealt round-robin
+        // to the 8 XCDs -- are spread over `spread`/1024 of the sweep
+        SbBin bn;
+        bn.s0 = s0; bn.s1 = s1;
+        bn.nb = (s1 - s0 + SB_DEPTH - 1) / SB_DEPTH;
+        bn.off = (uint32_t)(((uint64_t)((lin_block() / 8) % 32) * bn.nb * spread) >> 15);
         if (s1 > s0) {                               // first three batches: tickets wave, wave + W, wave + 2 W; moving before the bin is zeroed
-            sb_stream<WIDE>(a, wave, s0, s1, lane, val, cr, lrowW, stepBase);
-            sb_stream<WIDE>(b, wave + SB_WAVES, s0, s1, lane, val, cr, lrowW, stepBase);
-            sb_stream<WIDE>(c, wave + 2 * SB_WAVES, s0, s1, lane, val, cr, lrowW, stepBase);
+            sb_stream<WIDE>(a, wave, bn, lane, val, cr, lrowW, stepBase);
+            sb_stream<WIDE>(b, wave + SB_WAVES, bn, lane, val, cr, lrowW, stepBase);
+            sb_stream<WIDE>(c, wave + 2 * SB_WAVES, bn, lane, val, cr, lrowW, stepBase);
         }
         for (uint32_t k = threadIdx.x; k < R; k += SB_THREADS) yb[k] = 0.0;
         if (threadIdx.x == 0) *ctr = 3 * SB_WAVES;
@@ -284,8 +314,10 @@ __global__ __launch_bounds__(SB_THREADS) void sb_spmv_kernel(
 #ifdef SPMV_SB_DEBUG
             const uint32_t quarter = (s1 - s0) / 4;
             uint32_t nextMark = 1;
-#define SB_PROGRESS(S) do { if (lane == 0 && nextMark < 4 && (S).first - s0 >= nextMark * quarter) { SB_STAMP(1 + nextMark); } \
-                            while (nextMark < 4 && (S).first - s0 >= nextMark * quarter) ++nextMark; } while (0)
+            // progress = tickets handed out so far (the sweep starts anywhere in the bin and wraps around)
+#define SB_PROGRESS(S) do { const uint32_t done_ = (uint32_t)__builtin_amdgcn_readfirstlane((int)*(volatile uint32_t*)ctr) * SB_DEPTH;   \
+                            if (lane == 0 && nextMark < 4 && done_ >= nextMark * quarter) { SB_STAMP(1 + nextMark); }                    \
+                            while (nextMark < 4 && done_ >= nextMark * quarter) ++nextMark; } while (0)
 #else
 #define SB_PROGRESS(S) do { } while (0)
 #endif
@@ -293,7 +325,7 @@ __global__ __launch_bounds__(SB_THREADS) void sb_spmv_kernel(
 #define SB_STAGE(CUR, NXT, FAR, GC, GN)                                                            \
             if (CUR.first >= s1) break;                                                            \
             sb_gather<WIDE>(GN, NXT, x);                                                           \
-            sb_stream<WIDE>(FAR, sb_ticket(ctr, lane), s0, s1, lane, val, cr, lrowW, stepBase);    \
+            sb_stream<WIDE>(FAR, sb_ticket(ctr, lane), bn, lane, val, cr, lrowW, stepBase);        \
             sb_add<WIDE>(yb, CUR, GC, s1);                                                         \
             SB_PROGRESS(CUR);
             for (;;) {
@@ -326,11 +358,11 @@ struct TempBuf {
 // Bins: consecutive rows, (nearly) equal entry counts, at most SB_R_MAX rows.  Equal counts are what keeps the
 // workgroups of one XCD at the same place of their column sweeps; the bin count is a multiple of the CU count
 // (one workgroup per CU at a time: bins run in rounds) once the matrix is large enough for a full round.
-bool planBins(const std::vector<uint64_t>& irp, uint64_t M, uint32_t rMax, std::vector<uint32_t>& binRow) {
+bool planBins(const std::vector<uint64_t>& irp, uint64_t M, uint32_t rMax, uint32_t cus, std::vector<uint32_t>& binRow) {
     const uint64_t nnz = irp[M];
-    uint64_t B = std::max<uint64_t>((M + rMax - 1) / rMax, std::min<uint64_t>(SB_CUS, (nnz + SB_MIN_BIN_NNZ - 1) / SB_MIN_BIN_NNZ));
+    uint64_t B = std::max<uint64_t>((M + rMax - 1) / rMax, std::min<uint64_t>(cus, (nnz + SB_MIN_BIN_NNZ - 1) / SB_MIN_BIN_NNZ));
     B = std::max<uint64_t>(1, std::min<uint64_t>(B, M));
-    if (B > SB_CUS) B = (B + SB_CUS - 1) / SB_CUS * SB_CUS;
+    if (B > cus) B = (B + cus - 1) / cus * cus;
     if (B > M) B = M;
     if (B >= (1ull << 31)) return false;
     binRow.assign(B + 1, 0);
@@ -431,7 +463,9 @@ int buildStripes(DevMat* d) {
     uint32_t rMax = SB_R_MAX;
     if (const char* e = getenv("SPMV_SB_ROWS")) { const int v = atoi(e); if (v >= 1 && v <= (int)SB_R_MAX) rMax = (uint32_t)v; }     // tuning only
     std::vector<uint32_t> binRow;
-    if (!planBins(irp, M, rMax, binRow)) { fprintf(stderr, "libspmvhip: stripes: cannot cut %lu rows into bins\n", (unsigned long)M); return EXIT_FAILURE; }
+    uint32_t cus = SB_CUS;                           // workgroups that will walk the bins (one per CU): the bin count is a multiple of it
+    if (const char* e = getenv("SPMV_SB_GRID")) { const int v = atoi(e); if (v >= 1 && v <= (int)SB_CUS) cus = (uint32_t)v; }         // tuning only
+    if (!planBins(irp, M, rMax, cus, binRow)) { fprintf(stderr, "libspmvhip: stripes: cannot cut %lu rows into bins\n", (unsigned long)M); return EXIT_FAILURE; }
     const uint32_t B = (uint32_t)binRow.size() - 1;
     std::vector<uint64_t> binStart(B + 1);
     std::vector<uint32_t> binStep(B + 1);
@@ -518,14 +552,22 @@ int enqueueStripes(DevMat* d, const double* x, double* y, hipStream_t stream) {
         if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return EXIT_FAILURE;
         cus = std::max(1, prop.multiProcessorCount);
     }
-    const uint32_t grid = std::min<uint32_t>(f->B, (uint32_t)cus);
+    uint32_t grid = std::min<uint32_t>(f->B, (uint32_t)cus);
+    if (const char* e = getenv("SPMV_SB_GRID")) { const int v = atoi(e); if (v >= 1 && v <= cus) grid = std::min<uint32_t>(f->B, (uint32_t)v); }   // tuning only
     const size_t lds = (size_t)8 * f->R + 16;
+    // Start of the sweeps: the workgroups of one XCD begin SB_SPREAD/1024 of the bin apart in all (0.6 %, wrapping around).
+    // Started together they all ask L2 for the same lines in the same microsecond and every one of them waits for the
+    // fabric; a few microseconds apart the first to arrive pays and the rest hit: the first quarter of a bin 113 instead
+    // of 123 us and the bin 404 instead of 417 us on c3 (scripts/stripes_outliers.py).  Past ~2 % the tail of the pack
+    // outlives its lines in the 4 MiB L2 (c3: 6.4 % 1.05 ms, 100 % 2.96 ms; profiles/r02_stripes_spread.log).
+    uint32_t spread = SB_SPREAD;
+    if (const char* e = getenv("SPMV_SB_SPREAD")) { const int v = atoi(e); if (v >= 0 && v <= 1024) spread = (uint32_t)v; }          // tuning only
     if (f->wide)
         hipLaunchKernelGGL(sb_spmv_kernel<true>, dim3(grid), dim3(SB_THREADS), lds, stream, f->B, f->binRow, f->binStep, f->val, f->cr,
-                           f->lrowW, f->stepBase, x, y, f->R);
+                           f->lrowW, f->stepBase, x, y, f->R, spread);
     else
         hipLaunchKernelGGL(sb_spmv_kernel<false>, dim3(grid), dim3(SB_THREADS), lds, stream, f->B, f->binRow, f->binStep, f->val, f->cr,
-                           f->lrowW, f->stepBase, x, y, f->R);
+                           f->lrowW, f->stepBase, x, y, f->R, spread);
     return hipGetLastError() == hipSuccess ? EXIT_SUCCESS : EXIT_FAILURE;
 }
 

@@ -564,6 +564,29 @@ def test_stripes_many_small_bins(api, oracle, name, monkeypatch):
     assert tight_error(IRP, JA, AS, x, y_ref, y) <= TIGHT
 
 
+@pytest.mark.parametrize("spread,grid,rows", [(0, None, None), (1024, None, None), (1024, 3, 64), (517, 5, 200), (6, 1, 64)])
+def test_stripes_rotated_sweeps(api, oracle, spread, grid, rows, monkeypatch):
+    """The stripes kernel starts every workgroup's sweep somewhere inside the bin and wraps around (tuning knob
+    SPMV_SB_SPREAD: 1/1024ths of the bin over which one XCD's workgroups are spread).  Every entry must still be added
+    exactly once: no spread, the full bin, bins of one or two batches, and persistent grids of 1, 3 and 5 workgroups
+    (SPMV_SB_GRID) walking many bins each."""
+    monkeypatch.setenv("SPMV_SB_SPREAD", str(spread))
+    if grid:
+        monkeypatch.setenv("SPMV_SB_GRID", str(grid))
+    if rows:
+        monkeypatch.setenv("SPMV_SB_ROWS", str(rows))
+    for name in ("irregular", "wide", "banded", "ones", "uniform32"):
+        M, N, IRP, JA, AS = CASES[name]
+        x = _x(np.random.default_rng(23), N)
+        y_ref = oracle.csr_serial(IRP, JA, AS, x)
+        dmat = api.spMatCpyCSR(api.HostCSR(M, N, IRP, JA, AS))
+        y = _run(api, "hipSpMVStripesCSR", dmat, x, M)
+        dmat.free()
+        assert not np.isnan(y).any(), name
+        assert np.max(np.abs(y - y_ref), initial=0.0) <= GATE, name
+        assert tight_error(IRP, JA, AS, x, y_ref, y) <= TIGHT, name
+
+
 def test_tiles_build_options(api, oracle):
     """spmvHipBuildTilesOpt: options are arguments of the build (no process state), an explicit build replaces the format,
     out-of-range options are refused, and spmvHipTilesInfo reports what was built."""
