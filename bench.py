@@ -181,7 +181,8 @@ def format_info(api, dm, launcher):
     """device bytes and one-time build time of the launcher's private copy of the matrix"""
     if launcher == "hipSpMVTilesCSR":
         i = api.tiles_info(dm)
-        return {"extra_device_bytes": int(i.bytes), "format_build_ms": float(i.buildMs), "bins": int(i.nBins), "rows_per_bin": int(i.rowsPerBin),
+        return {"extra_device_bytes": int(i.bytes), "format_build_ms": float(i.buildMs), "format_build_alloc_ms": float(getattr(i, "allocMs", 0.0)),
+                "bins": int(i.nBins), "rows_per_bin": int(i.rowsPerBin),
                 "phase1_work_item_entries": int(i.chunk), "product_workspace_bytes": int(dm.nnz) * 8}
     if launcher == "hipSpMVStripesCSR":
         nb, rpb, wide, ms = C.c_uint(), C.c_uint(), C.c_int(), C.c_double()
@@ -589,7 +590,8 @@ def run_single(args, api, synth, torch, w):
                      "algorithmic_bytes_per_launch": res["algorithmic_bytes"],
                      "kernel_ms_avg": res["kernel_ms_avg"], "kernel_ms_var": res["kernel_ms_var"],
                      "kernel_ms_phases": res.get("kernel_ms_phases"),
-                     "format_build_ms": res.get("format_build_ms"), "extra_device_bytes": res.get("extra_device_bytes")},
+                     "format_build_ms": res.get("format_build_ms"), "format_build_alloc_ms": res.get("format_build_alloc_ms"),
+                     "extra_device_bytes": res.get("extra_device_bytes")},
         "parity": res["parity"],
     }
     if "cpu_baseline" in res:

@@ -257,8 +257,10 @@ typedef struct {
     unsigned nBins, rowsPerBin, nSlices;
     int      taper, ntStore;
     unsigned chunk;
-    double   buildMs;          /* device time of the one-time build */
+    double   buildMs;          /* wall time of the one-time build, allocations included */
     size_t   bytes;            /* device memory of the format (the shared product workspace not included) */
+    double   allocMs;          /* the part of buildMs the host spent in hipMalloc: format, product workspace and 36 B per
+                                * entry of temporaries (c5: ~90 GB mapped -- seconds; the build kernels themselves ~0.1 s) */
 } spmvTilesInfo;
 int spmvHipTilesInfo(spmat* dMat, spmvTilesInfo* info);   /* zeros when the format has not been built */
 int spmvHipTilesBinRow(spmat* dMat, unsigned bin, ulong* firstRow);

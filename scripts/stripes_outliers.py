@@ -67,6 +67,20 @@ def show(tag, idx):
     print(f"   bin duration: median {np.median(dur):.1f}  p95 {np.percentile(dur, 95):.1f}  max {dur.max():.1f}")
 
 
+# who straggles?  (HW_ID: CU_ID bits 11:8, SH_ID 12, SE_ID 15:13)
+med = np.median(times)
+print("stragglers of the slow launches (kernel > 1.05 x median): launch, ms, bin, xcc, se, sh, cu, duration us")
+for i in np.nonzero(times > 1.05 * med)[0]:
+    ms, d = runs[i]
+    t = d[:, 1:6].astype(np.float64) / 100.0
+    dur = t[:, 4] - t[:, 0]
+    b = int(np.argmax(dur))
+    hw = int(d[b, 0] & np.uint64(0xFFFFFFFF))
+    print(f"   {i:3d} {ms:.3f} bin {b:3d} wg {b % 256:3d} xcc {int(d[b, 0] >> np.uint64(32))} se {(hw >> 13) & 7} sh {(hw >> 12) & 1} cu {(hw >> 8) & 15}  {dur[b]:.1f}")
+# placement of workgroup -> CU in the last launch
+d = runs[-1][1]
+hw = (d[:256, 0] & np.uint64(0xFFFFFFFF)).astype(np.int64)
+print("placement (last launch) wg: xcc/se/cu for wgs 0..31:", " ".join(f"{int(d[i, 0] >> np.uint64(32))}/{(int(hw[i]) >> 13) & 7}/{(int(hw[i]) >> 8) & 15}" for i in range(32)))
 show("typical", order[len(order) // 2])
 show("slowest", order[-1])
 show("second slowest", order[-2])

@@ -98,7 +98,7 @@ class spmvTilesOpts(C.Structure):
 
 class spmvTilesInfo(C.Structure):
     _fields_ = [("nBins", C.c_uint), ("rowsPerBin", C.c_uint), ("nSlices", C.c_uint), ("taper", _i), ("ntStore", _i),
-                ("chunk", C.c_uint), ("buildMs", C.c_double), ("bytes", _sz)]
+                ("chunk", C.c_uint), ("buildMs", C.c_double), ("bytes", _sz), ("allocMs", C.c_double)]
 
 
 IPC_HANDLE_BYTES = 64

@@ -37,6 +37,7 @@
 #include <hip/hip_runtime.h>
 #include <cstring>
 #include <cmath>
+#include <chrono>
 #include <rocprim/device/device_radix_sort.hpp>
 #include <rocprim/device/device_scan.hpp>
 #include <algorithm>
@@ -98,7 +99,8 @@ struct TileFormat {
     size_t    bytes = 0;
     spmvTilesOpts opts{0, 0, -1, 0};                // what the format was built with (0 / -1 = automatic)
     uint32_t  chunk = 0;                            // phase-1 work item size in entries actually used
-    double    buildMs = 0;                          // device time of the one-time build
+    double    buildMs = 0;                          // wall time of the one-time build (events on the null stream around it)
+    double    allocMs = 0;                          // ... of which the host spent in hipMalloc (format, product workspace, 36 B/entry of temporaries)
 };
 
 struct TileDst { double* p[SPMV_MAX_PEERS]; uint32_t n; };
@@ -725,6 +727,7 @@ int buildTiles(DevMat* d, const spmvTilesOpts* opts) {
 
     TempBuf keys, keysOut, pay, payOut, sortTmp, tileStart;
     auto fail = [&](const char* what) { fprintf(stderr, "libspmvhip: tiles: %s failed\n", what); return EXIT_FAILURE; };
+    const auto allocT0 = std::chrono::steady_clock::now();
     if (keys.alloc(nnz * 2) || keysOut.alloc(nnz * 2) || pay.alloc(nnz * sizeof(PbPay)) || payOut.alloc(nnz * sizeof(PbPay)) ||
         tileStart.alloc((nTiles + 2) * 4))
         return fail("temporary allocation (36 B per entry while the format is built)");
@@ -732,6 +735,7 @@ int buildTiles(DevMat* d, const spmvTilesOpts* opts) {
         !prodWorkspace(nnz, true) || hipMalloc(&t->binPos, ((size_t)t->B + 1) * 4) ||
         hipMalloc(&t->waveTile, (size_t)t->B * P2_WAVES * 4))
         return fail("format allocation");
+    t->allocMs = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - allocT0).count();
 
     if (d->irpBytes == 4)
         hipLaunchKernelGGL((pb_payload_kernel<uint32_t>), grid2d((M + 3) / 4, 256), dim3(256), 0, nullptr, M, static_cast<const uint32_t*>(d->IRP), d->JA, d->AS,
@@ -900,7 +904,7 @@ void tilesInfo(const DevMat* d, spmvTilesInfo* out) {
     const TileFormat* t = d->tiles;
     if (!t) return;
     out->nBins = t->B; out->rowsPerBin = t->R; out->nSlices = t->S; out->taper = t->bins.n1 != 0; out->ntStore = t->ntStore;
-    out->chunk = t->chunk; out->buildMs = t->buildMs; out->bytes = t->bytes;
+    out->chunk = t->chunk; out->buildMs = t->buildMs; out->bytes = t->bytes; out->allocMs = t->allocMs;
 }
 
 void tilesShape(const DevMat* d, uint32_t* bins, uint32_t* rowsPerBin) {

@@ -564,6 +564,60 @@ def test_stripes_many_small_bins(api, oracle, name, monkeypatch):
     assert tight_error(IRP, JA, AS, x, y_ref, y) <= TIGHT
 
 
+def _fuzz_case(seed):
+    """Seeded random shape: 1..4000 rows, 1..200 000 columns, row lengths from a mix of laws (many empty rows, a
+    geometric body, a few rows as long as the matrix allows), sorted distinct columns."""
+    rng = np.random.default_rng(seed)
+    M = int(rng.choice([1, 2, 63, 64, 65, int(rng.integers(1, 4000))]))
+    N = int(rng.choice([1, 2, 17, 4096, int(rng.integers(1, 200_000))]))
+    law = seed % 4
+    if law == 0:
+        lens = rng.geometric(0.15, size=M) - 1
+    elif law == 1:
+        lens = np.where(rng.random(M) < 0.6, 0, rng.integers(0, 50, size=M))
+    elif law == 2:
+        lens = np.full(M, int(rng.integers(0, 70)))
+    else:
+        lens = (rng.pareto(1.2, size=M) * 3).astype(np.int64)
+    lens = np.minimum(lens, N).astype(np.int64)
+    for _ in range(3):                                     # a few rows as long as the matrix allows (capped)
+        lens[int(rng.integers(0, M))] = min(N, int(rng.integers(1, 6000)))
+    return (M, N) + random_csr(rng, M, N, lens)
+
+
+@pytest.mark.parametrize("seed", list(range(24)))
+def test_fuzz_random_shapes(api, oracle, seed):
+    """Every CSR launcher, and the ELL launchers when the longest row is short enough for a padded copy, on seeded random
+    shapes (sizes that are no multiple of anything, one row, one column, mostly empty, uniform, heavy-tailed)."""
+    M, N, IRP, JA, AS = _fuzz_case(seed)
+    x = _x(np.random.default_rng(1000 + seed), N)
+    y_ref = oracle.csr_serial(IRP, JA, AS, x)
+    dmat = api.spMatCpyCSR(api.HostCSR(M, N, IRP, JA, AS))
+    for launcher in ("hipSpMVRowsCSR", "hipSpMVWarpPerRowCSR", "hipSpMVTilesCSR", "hipSpMVStripesCSR", "hipSpMVRowsSELL"):
+        if launcher in ("hipSpMVTilesCSR", "hipSpMVStripesCSR") and JA.size == 0:
+            continue                                      # these formats need at least one entry (refused with a message)
+        y = _run(api, launcher, dmat, x, M)
+        assert not np.isnan(y).any(), (seed, launcher)
+        assert np.max(np.abs(y - y_ref), initial=0.0) <= GATE, (seed, launcher)
+        if launcher == "hipSpMVRowsCSR":
+            assert np.array_equal(y, y_ref), (seed, launcher)
+        else:
+            assert tight_error(IRP, JA, AS, x, y_ref, y) <= TIGHT, (seed, launcher)
+    dmat.free()
+    if JA.size and int(np.diff(IRP.astype(np.int64)).max()) * M <= 4_000_000:
+        for rowlens in (True, False):
+            ell = api.HostCSR(M, N, IRP, JA, AS).to_ell(with_row_lens=rowlens)
+            api.lib.spmvHipSetEllRowLens(1 if rowlens else 0)
+            for launcher, transposed in (("hipSpMVRowsELL", True), ("hipSpMVRowsELLNNTransposed", False),
+                                         ("hipSpMVWarpsPerRowELLNTrasposed", False)):
+                d = api.spMatCpyELL(ell.transpose() if transposed else ell)
+                y = _run(api, launcher, d, x, M)
+                d.free()
+                assert not np.isnan(y).any(), (seed, launcher, rowlens)
+                assert tight_error(IRP, JA, AS, x, y_ref, y) <= TIGHT, (seed, launcher, rowlens)
+        api.lib.spmvHipSetEllRowLens(1)
+
+
 @pytest.mark.parametrize("spread,grid,rows", [(0, None, None), (1024, None, None), (1024, 3, 64), (517, 5, 200), (6, 1, 64)])
 def test_stripes_rotated_sweeps(api, oracle, spread, grid, rows, monkeypatch):
     """The stripes kernel starts every workgroup's sweep somewhere inside the bin and wraps around (tuning knob
