@@ -19,6 +19,10 @@
 //     x that stays in an XCD's L2.  Bit-identical and correct -- and no faster on config 2: 0.232 ms against 0.237.
 //     With one lane per row the 64 lanes of a gather touch 64 different lines whatever cache serves them, and the rate
 //     at which a CU's L1 takes lines from L2 (~0.3 per clock) is the bound, not where the lines come from;)
+//   * (tried and removed, round 2: slices stored in groups of 4 slots -- entry k of lane l at (k/4)*256 + l*4 + k%4 -- so
+//     that a lane fetches 4 columns with one 16-byte load and 4 values with two: 7 instead of 12 vector-memory
+//     instructions per 4 entries, bit-identical, c2 0.244 ms against 0.238.  The coalesced loads are not what the L1
+//     spends its time on; the 64-line gathers are;)
 //   * rows longer than SELL_MAX_ROW do not enter the slices (one of them would pin a wavefront for
 //     a whole slice): they are processed workgroup-per-row from the CSR arrays (shuffle tree).
 #include <hip/hip_runtime.h>
