@@ -470,6 +470,19 @@ def measure_block(api, synth, torch, w, launcher, steps, warmup, candidates=None
         f"max|dy|={parity['max_abs_diff']:.2e} max|dy|/sum|ax|={parity['max_diff_over_sum_abs_ax']:.2e}")
     if not parity["ok"]:
         raise SystemExit(f"PARITY FAILURE on {w.name} [{res['launcher']}]: {parity}")
+    if res["auto_candidates_ms"] and hasattr(api.lib, "hipSpMVAutoCSR"):
+        # what a caller of the C-ABI's own selector gets for this matrix (hipSpMVAutoCSR measures inside the library at
+        # its first call; SELL is not among its candidates) -- after the timed launcher's y has been checked, checked itself
+        ms3 = (C.c_double * 3)()
+        y_t.fill_(float("nan"))
+        if api.lib.hipSpMVAutoCSR(C.byref(ctx["dm"].handle), ctx["x"].data_ptr(), api.CONFIG(), y_t.data_ptr()) == 0:
+            torch.cuda.synchronize()
+            name = api.lib.spmvHipAutoChoice(C.byref(ctx["dm"].handle), ms3)
+            par2 = win.check(lambda a, b: y_t[a:b].cpu().numpy())
+            res["library_auto_choice"] = {"launcher": name.decode() if name else None, "parity_ok": bool(par2["ok"]),
+                                          "ms": dict(zip(("hipSpMVWarpPerRowCSR", "hipSpMVTilesCSR", "hipSpMVStripesCSR"), [float(v) for v in ms3]))}
+            if not par2["ok"]:
+                raise SystemExit(f"PARITY FAILURE on {w.name} [hipSpMVAutoCSR -> {name}]: {par2}")
     ctx["dm"].free()
     del ctx
     torch.cuda.empty_cache()

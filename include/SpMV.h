@@ -39,6 +39,8 @@ extern "C" {
 #define HIP_SELL_ROWS           "HIP_SELL_ROWS"
 #define CUDA_CSR_STRIPES        "CUDA_CSR_STRIPES"                 /* new: one-pass stripes kernel (y bins in LDS, x from the XCD's L2) */
 #define HIP_CSR_STRIPES         "HIP_CSR_STRIPES"
+#define CUDA_CSR_AUTO           "CUDA_CSR_AUTO"                    /* new: the fastest CSR launcher for the matrix, by measurement */
+#define HIP_CSR_AUTO            "HIP_CSR_AUTO"
 #define HIP_CSR_ROWS            "HIP_CSR_ROWS"
 #define HIP_CSR_ROWS_WARP       "HIP_CSR_ROWS_WARP"
 #define HIP_ELL_ROWS            "HIP_ELL_ROWS"
@@ -63,6 +65,7 @@ typedef enum {              /* same order and values as SpMV.h:42-59 */
     _CUDA_CSR_TILES,        /* appended: column-sliced two-phase CSR */
     _CUDA_SELL_ROWS,        /* appended: SELL-C-sigma built from the CSR upload */
     _CUDA_CSR_STRIPES,      /* appended: one-pass stripes CSR */
+    _CUDA_CSR_AUTO,         /* appended: hipSpMVAutoCSR */
     _COMPUTE_MODE_INVALID = -1
 } COMPUTE_MODE;
 
@@ -71,7 +74,7 @@ COMPUTE_MODE spmvModeFromString(const char* name);
 static inline int spmvModeIsGpu(COMPUTE_MODE m) { return m >= _CUDA_CSR_ROWS; }
 static inline int spmvModeIsCsr(COMPUTE_MODE m) {
     return m <= _CSR_TILES_ALLOCD || m == _CUDA_CSR_ROWS || m == _CUDA_CSR_ROWS_WARP || m == _CUDA_CSR_TILES ||
-           m == _CUDA_SELL_ROWS || m == _CUDA_CSR_STRIPES;
+           m == _CUDA_SELL_ROWS || m == _CUDA_CSR_STRIPES || m == _CUDA_CSR_AUTO;
 }
 
 /* y = A x: (matrix, x, run configuration, y) -> EXIT_SUCCESS / EXIT_FAILURE */
@@ -85,11 +88,13 @@ static const SPMV_HIP_INTERF SpmvCUDA_CSRFuncs[] = {
     &hipSpMVTilesCSR,           /* appended: no counterpart in the reference's GPU table */
     &hipSpMVRowsSELL,           /* appended: SELL-C-sigma copy of the CSR matrix */
     &hipSpMVStripesCSR,         /* appended: one-pass stripes kernel */
+    &hipSpMVAutoCSR,            /* appended: the fastest of the above for the matrix at hand */
 };
 #define SpmvCUDA_CSRFuncs_WarpPerRowIdx     1
 #define SpmvCUDA_CSRFuncs_TilesIdx          2
 #define SpmvCUDA_CSRFuncs_SellIdx           3
 #define SpmvCUDA_CSRFuncs_StripesIdx        4
+#define SpmvCUDA_CSRFuncs_AutoIdx           5
 static const SPMV_HIP_INTERF SpmvCUDA_ELLFuncs[] = {
     &hipSpMVRowsELL,
     &hipSpMVRowsELLNNTransposed,

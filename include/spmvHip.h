@@ -138,6 +138,18 @@ size_t spmvHipStripesBytes(spmat* dMat);
  * encoding with 32-bit columns had to be used, device time of the one-time build in ms */
 int    spmvHipStripesShape(spmat* dMat, unsigned* nBins, unsigned* rowsPerBin, int* wide, double* buildMs);
 
+/* The fastest CSR launcher for THIS matrix, chosen by measurement at the first call for a handle (the reference's
+ * callers choose a kernel by name -- CUDA_CSR_ROWS_WARP, ... -- src/main.cu:103-139; which of this library's kernels
+ * wins depends on where x lives relative to the caches, DESIGN.md sections 4, 7, 8).  Candidates: hipSpMVWarpPerRowCSR
+ * always; from 2^18 entries on hipSpMVTilesCSR and, while x (N * 8 B) fits the 256 MiB Infinity Cache,
+ * hipSpMVStripesCSR.  The first call runs every eligible candidate on the caller's x (one launch that also builds its
+ * format + 3 timed ones; each leaves the complete y), keeps the fastest and frees the private formats of the others;
+ * it synchronises the stream even after spmvHipSetSync(0).  Later calls go straight to the chosen launcher.
+ * spmvHipAutoChoice: its name (NULL before the first call) and, if msPerCandidate != NULL, the three measured times in
+ * ms in the order above (0 = not eligible / not tried).  Arrival-order sums when a format kernel wins. */
+SPMV_HIP hipSpMVAutoCSR;
+const char* spmvHipAutoChoice(spmat* dMat, double* msPerCandidate);
+
 /* SELL-C-sigma (C = 64 rows per slice = one wavefront, rows sorted by length inside 16 Ki-row
  * windows, column-major inside a slice) built on the device from an uploaded CSR handle at the
  * first call: the ELL-family kernel for matrices whose longest row makes plain ELL impossible

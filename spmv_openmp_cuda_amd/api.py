@@ -58,6 +58,7 @@ _sigs = {
     "hipSpMVTilesCSR": (_SPMV_ARGS, _i), "spmvHipBuildTiles": ([C.POINTER(spmat)], _i),
     "spmvHipTilesBytes": ([C.POINTER(spmat)], _sz),
     "hipSpMVStripesCSR": (_SPMV_ARGS, _i), "spmvHipBuildStripes": ([C.POINTER(spmat)], _i),
+    "hipSpMVAutoCSR": (_SPMV_ARGS, _i), "spmvHipAutoChoice": ([C.POINTER(spmat), C.POINTER(C.c_double)], C.c_char_p),
     "spmvHipStripesBytes": ([C.POINTER(spmat)], _sz),
     "spmvHipStripesShape": ([C.POINTER(spmat), C.POINTER(C.c_uint), C.POINTER(C.c_uint), C.POINTER(_i), C.POINTER(C.c_double)], _i),
     "spmvHipEnqueueCSR": ([C.POINTER(spmat), _i, _vp, _vp, _vp], _i),
@@ -136,6 +137,7 @@ SPMV_LAUNCHERS = {
     "hipSpMVWarpPerRowCSR": lib.hipSpMVWarpPerRowCSR,
     "hipSpMVTilesCSR": lib.hipSpMVTilesCSR,
     "hipSpMVStripesCSR": lib.hipSpMVStripesCSR,
+    "hipSpMVAutoCSR": lib.hipSpMVAutoCSR,
     "hipSpMVRowsSELL": lib.hipSpMVRowsSELL,
     "hipSpMVRowsELL": lib.hipSpMVRowsELL,
     "hipSpMVRowsELLNNTransposed": lib.hipSpMVRowsELLNNTransposed,

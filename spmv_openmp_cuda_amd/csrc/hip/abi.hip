@@ -666,6 +666,71 @@ int hipSpMVTilesCSR(spmat* dMat, double* dX, CONFIG cfg, double* dY) {
     return L.finish("hipSpMVTilesCSR");
 }
 
+// ---- hipSpMVAutoCSR: the fastest CSR launcher for THIS matrix, found by timing ----------------------------------
+// Which kernel wins depends on where x lives relative to the caches (DESIGN.md sections 4, 7, 8): the LDS-stream
+// kernel when the columns of neighbouring rows meet in L1/L2 (narrow bands, small matrices), the stripes kernel
+// while x fits the Infinity Cache, the two-phase kernel beyond.  A caller of the reference picks a kernel by name
+// (CUDA_CSR_ROWS_WARP ...); this entry point picks by measurement, once per handle, on the caller's own x: every
+// eligible candidate computes y (one warm-up launch that also builds its format, AUTO_REPS timed ones), the fastest
+// stays, the formats of the others are released, and the chosen launcher runs once more so that y is its own.  The
+// first call is a normal -- slow -- SpMV and synchronises the stream even in enqueue-only mode.
+namespace {
+constexpr int      AUTO_N = 3, AUTO_REPS = 3;
+constexpr uint64_t AUTO_MIN_NNZ = 1ull << 18;        // below this a launch is mostly latency: no private format pays
+constexpr uint64_t AUTO_STRIPES_X_BYTES = 256ull << 20;   // the stripes kernel re-reads x once per XCD and round of bins
+struct AutoCand { const char* name; SPMV_HIP* fn; };
+const AutoCand AUTO_CAND[AUTO_N] = {{"hipSpMVWarpPerRowCSR", &hipSpMVWarpPerRowCSR}, {"hipSpMVTilesCSR", &hipSpMVTilesCSR},
+                                    {"hipSpMVStripesCSR", &hipSpMVStripesCSR}};
+
+int autoSelect(spmat* dMat, DevMat* d, double* dX, CONFIG cfg, double* dY) {
+    const bool fmtOk = d->NZ >= AUTO_MIN_NNZ && d->NZ < IRP32_LIMIT;
+    const bool eligible[AUTO_N] = {true, fmtOk, fmtOk && d->N * 8 <= AUTO_STRIPES_X_BYTES};
+    if (!fmtOk) { d->autoPick = 0; return EXIT_SUCCESS; }
+    const bool hadTiles = d->tiles != nullptr, hadStripes = d->stripes != nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    HIP_TRY(hipEventCreate(&e0));
+    if (hipEventCreate(&e1) != hipSuccess) { (void)hipEventDestroy(e0); ERR("hipSpMVAutoCSR: event creation failed"); return EXIT_FAILURE; }
+    int best = -1;
+    float bestMs = 0;
+    for (int c = 0; c < AUTO_N; ++c) {
+        if (!eligible[c]) continue;
+        if (AUTO_CAND[c].fn(dMat, dX, cfg, dY)) continue;            // warm-up + format build; a candidate that fails is not a candidate
+        bool ok = hipEventRecord(e0, S.stream) == hipSuccess;
+        for (int r = 0; ok && r < AUTO_REPS; ++r) ok = AUTO_CAND[c].fn(dMat, dX, cfg, dY) == EXIT_SUCCESS;
+        float ms = 0;
+        ok = ok && hipEventRecord(e1, S.stream) == hipSuccess && hipEventSynchronize(e1) == hipSuccess &&
+             hipEventElapsedTime(&ms, e0, e1) == hipSuccess;
+        if (!ok) continue;
+        d->autoMs[c] = ms / AUTO_REPS;
+        if (best < 0 || ms < bestMs) { best = c; bestMs = ms; }
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    if (best < 0) { ERR("hipSpMVAutoCSR: no candidate kernel ran"); return EXIT_FAILURE; }
+    // the losers' private copies of the matrix (12 B/nnz each) go; formats the caller built before stay
+    if (best != 1 && d->tiles && !hadTiles) { freeTiles(d->tiles); d->tiles = nullptr; }
+    if (best != 2 && d->stripes && !hadStripes) { freeStripes(d->stripes); d->stripes = nullptr; }
+    d->autoPick = best;
+    return EXIT_SUCCESS;
+}
+}  // namespace
+
+int hipSpMVAutoCSR(spmat* dMat, double* dX, CONFIG cfg, double* dY) {
+    DevMat* d = descOf(dMat, "hipSpMVAutoCSR");
+    if (!d) return EXIT_FAILURE;
+    if (d->kind != Kind::CSR) { ERR("hipSpMVAutoCSR: handle is not CSR"); return EXIT_FAILURE; }
+    if (d->M == 0) return EXIT_SUCCESS;
+    if (d->autoPick < 0 && autoSelect(dMat, d, dX, cfg, dY)) return EXIT_FAILURE;
+    return AUTO_CAND[d->autoPick].fn(dMat, dX, cfg, dY);               // (also after the selection: y then is the chosen kernel's own)
+}
+
+const char* spmvHipAutoChoice(spmat* dMat, double* msPerCandidate) {
+    DevMat* d = descOf(dMat, "spmvHipAutoChoice");
+    if (!d || d->autoPick < 0) return nullptr;
+    if (msPerCandidate) for (int c = 0; c < AUTO_N; ++c) msPerCandidate[c] = d->autoMs[c];
+    return AUTO_CAND[d->autoPick].name;
+}
+
 static DevMat* tilesReady(spmat* dMat, const char* who) {
     DevMat* d = descOf(dMat, who);
     if (!d) return nullptr;

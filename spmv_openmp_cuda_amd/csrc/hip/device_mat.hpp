@@ -57,6 +57,8 @@ struct DevMat {
     TileFormat* tiles = nullptr;    // built lazily by hipSpMVTilesCSR / spmvHipBuildTiles
     SellFormat* sell = nullptr;     // built lazily by hipSpMVRowsSELL / spmvHipBuildSell
     StripeFormat* stripes = nullptr; // built lazily by hipSpMVStripesCSR / spmvHipBuildStripes
+    int       autoPick = -1;        // hipSpMVAutoCSR: index of the launcher chosen for this matrix (-1: not chosen yet)
+    float     autoMs[3] = {0, 0, 0}; // ... and what each candidate took (0 = not tried)
 };
 
 int  buildSell(DevMat* d);                                      // sell.hip

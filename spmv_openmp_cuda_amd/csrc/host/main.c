@@ -28,7 +28,7 @@ CONFIG Conf = {.gridRows = 8, .gridCols = 8};
 
 #define RNDVECT "RNDVECT"
 #define HELP "usage: MatrixMarket_sparse_matrix_COO, vectorFile || " RNDVECT ", [COMPUTE MODE:\n\tHIP:\t" \
-    CUDA_CSR_ROWS "," CUDA_CSR_ROWS_WARP "," CUDA_CSR_TILES "," CUDA_CSR_STRIPES "," CUDA_SELL_ROWS "," CUDA_ELL_ROWS "," CUDA_ELL_ROWS_NT "," CUDA_ELL_ROWS_WARP_NT \
+    CUDA_CSR_ROWS "," CUDA_CSR_ROWS_WARP "," CUDA_CSR_TILES "," CUDA_CSR_STRIPES "," CUDA_CSR_AUTO "," CUDA_SELL_ROWS "," CUDA_ELL_ROWS "," CUDA_ELL_ROWS_NT "," CUDA_ELL_ROWS_WARP_NT \
     " (HIP_* synonyms accepted)]\n"
 
 static long envLong(const char* name, long dflt) {
@@ -113,6 +113,7 @@ int main(int argc, char** argv) {
         case _CUDA_CSR_TILES:        func = &hipSpMVTilesCSR; break;
         case _CUDA_SELL_ROWS:        func = &hipSpMVRowsSELL; break;
         case _CUDA_CSR_STRIPES:      func = &hipSpMVStripesCSR; break;
+        case _CUDA_CSR_AUTO:         func = &hipSpMVAutoCSR; break;
         case _CUDA_ELL_ROWS:         func = &hipSpMVRowsELL; break;
         case _CUDA_ELL_ROWS_NT:      func = &hipSpMVRowsELLNNTransposed; break;
         case _CUDA_ELL_ROWS_WARP_NT: func = &hipSpMVWarpsPerRowELLNTrasposed; break;

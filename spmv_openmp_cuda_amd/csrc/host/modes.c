@@ -14,6 +14,7 @@ COMPUTE_MODE spmvModeFromString(const char* s) {
         {CUDA_CSR_TILES, _CUDA_CSR_TILES}, {HIP_CSR_TILES, _CUDA_CSR_TILES},
         {CUDA_SELL_ROWS, _CUDA_SELL_ROWS}, {HIP_SELL_ROWS, _CUDA_SELL_ROWS},
         {CUDA_CSR_STRIPES, _CUDA_CSR_STRIPES}, {HIP_CSR_STRIPES, _CUDA_CSR_STRIPES},
+        {CUDA_CSR_AUTO, _CUDA_CSR_AUTO}, {HIP_CSR_AUTO, _CUDA_CSR_AUTO},
         {HIP_CSR_ROWS, _CUDA_CSR_ROWS}, {HIP_CSR_ROWS_WARP, _CUDA_CSR_ROWS_WARP},
         {HIP_ELL_ROWS, _CUDA_ELL_ROWS}, {HIP_ELL_ROWS_NT, _CUDA_ELL_ROWS_NT},
         {HIP_ELL_ROWS_WARP_NT, _CUDA_ELL_ROWS_WARP_NT},

@@ -564,6 +564,50 @@ def test_stripes_many_small_bins(api, oracle, name, monkeypatch):
     assert tight_error(IRP, JA, AS, x, y_ref, y) <= TIGHT
 
 
+def test_auto_launcher_picks_and_remembers(api, oracle):
+    """hipSpMVAutoCSR: small matrices go to the LDS-stream kernel without a measurement; from 2^18 entries on the
+    eligible candidates are timed on the caller's x, the choice is reported and remembered, the losers' formats are
+    released, and y equals the oracle on the first call and on every later one."""
+    import ctypes as C
+    # small: no private format is ever built
+    M, N, IRP, JA, AS = CASES["irregular"]
+    x = _x(np.random.default_rng(31), N)
+    y_ref = oracle.csr_serial(IRP, JA, AS, x)
+    dmat = api.spMatCpyCSR(api.HostCSR(M, N, IRP, JA, AS))
+    assert api.lib.spmvHipAutoChoice(C.byref(dmat.handle), None) is None
+    y = _run(api, "hipSpMVAutoCSR", dmat, x, M)
+    assert tight_error(IRP, JA, AS, x, y_ref, y) <= TIGHT and not np.isnan(y).any()
+    assert api.lib.spmvHipAutoChoice(C.byref(dmat.handle), None) == b"hipSpMVWarpPerRowCSR"
+    assert api.lib.spmvHipTilesBytes(C.byref(dmat.handle)) == 0 and api.lib.spmvHipStripesBytes(C.byref(dmat.handle)) == 0
+    dmat.free()
+    # large enough to be measured: 2^18+ entries, uniform columns
+    rng = np.random.default_rng(32)
+    M2 = N2 = 40_000
+    IRP2, JA2, AS2 = random_csr(rng, M2, N2, np.full(M2, 8))
+    x2 = _x(rng, N2)
+    y2_ref = oracle.csr_serial(IRP2, JA2, AS2, x2)
+    d2 = api.spMatCpyCSR(api.HostCSR(M2, N2, IRP2, JA2, AS2))
+    ms = (C.c_double * 3)()
+    for call in range(3):
+        y2 = _run(api, "hipSpMVAutoCSR", d2, x2, M2)
+        assert not np.isnan(y2).any() and tight_error(IRP2, JA2, AS2, x2, y2_ref, y2) <= TIGHT, call
+        name = api.lib.spmvHipAutoChoice(C.byref(d2.handle), ms)
+        assert name in (b"hipSpMVWarpPerRowCSR", b"hipSpMVTilesCSR", b"hipSpMVStripesCSR")
+        assert all(t > 0 for t in ms), list(ms)                  # all three were eligible and measured
+        assert ms[(b"hipSpMVWarpPerRowCSR", b"hipSpMVTilesCSR", b"hipSpMVStripesCSR").index(name)] == min(ms)
+    # only the winner keeps a private copy of the matrix
+    tb, sb = api.lib.spmvHipTilesBytes(C.byref(d2.handle)), api.lib.spmvHipStripesBytes(C.byref(d2.handle))
+    assert (tb > 0) == (name == b"hipSpMVTilesCSR") and (sb > 0) == (name == b"hipSpMVStripesCSR")
+    d2.free()
+    # an ELL handle is refused
+    Me, Ne, IRPe, JAe, ASe = CASES["cage4-shaped"]
+    de = api.spMatCpyELL(api.HostCSR(Me, Ne, IRPe, JAe, ASe).to_ell())
+    dx, dy = api.DeviceVector(Ne), api.DeviceVector(Me)
+    with pytest.raises(api.SpmvHipError):
+        api.spmv("hipSpMVAutoCSR", de, dx, dy)
+    de.free()
+
+
 def _fuzz_case(seed):
     """Seeded random shape: 1..4000 rows, 1..200 000 columns, row lengths from a mix of laws (many empty rows, a
     geometric body, a few rows as long as the matrix allows), sorted distinct columns."""
@@ -593,7 +637,7 @@ def test_fuzz_random_shapes(api, oracle, seed):
     x = _x(np.random.default_rng(1000 + seed), N)
     y_ref = oracle.csr_serial(IRP, JA, AS, x)
     dmat = api.spMatCpyCSR(api.HostCSR(M, N, IRP, JA, AS))
-    for launcher in ("hipSpMVRowsCSR", "hipSpMVWarpPerRowCSR", "hipSpMVTilesCSR", "hipSpMVStripesCSR", "hipSpMVRowsSELL"):
+    for launcher in ("hipSpMVRowsCSR", "hipSpMVWarpPerRowCSR", "hipSpMVTilesCSR", "hipSpMVStripesCSR", "hipSpMVRowsSELL", "hipSpMVAutoCSR"):
         if launcher in ("hipSpMVTilesCSR", "hipSpMVStripesCSR") and JA.size == 0:
             continue                                      # these formats need at least one entry (refused with a message)
         y = _run(api, launcher, dmat, x, M)

@@ -20,7 +20,7 @@ HARNESS = os.path.join(ROOT, "tests", "harness", "test_SpMV_HIP.elf")
 
 
 @pytest.mark.parametrize("name", NAMES)
-@pytest.mark.parametrize("mode", ["CUDA_CSR_ROWS", "CUDA_CSR_ROWS_WARP", "HIP_CSR_TILES", "HIP_CSR_STRIPES", "HIP_SELL_ROWS", "CUDA_ELL_ROWS",
+@pytest.mark.parametrize("mode", ["CUDA_CSR_ROWS", "CUDA_CSR_ROWS_WARP", "HIP_CSR_TILES", "HIP_CSR_STRIPES", "CUDA_CSR_AUTO", "HIP_SELL_ROWS", "CUDA_ELL_ROWS",
                                   "HIP_ELL_ROWS_NN_TRANSPOSED", "CUDA_ELL_ROWS_WARP_NN_TRANSPOSED"])
 def test_cli_against_reference_cli_output(name, mode):
     g = load_golden(name)
@@ -71,7 +71,7 @@ def test_harness_all_implementations_pass(name):
                        capture_output=True, text=True, timeout=300, env=dict(os.environ, OMP_NUM_THREADS="4"))
     assert r.returncode == 0, r.stdout + r.stderr
     out = r.stdout
-    assert out.count("cudaBlockSize:") == 8 and out.count("threadNum:") == 8     # 5 CSR-upload + 3 ELL launchers; 5 + 3 OpenMP variants like the reference
+    assert out.count("cudaBlockSize:") == 9 and out.count("threadNum:") == 8     # 6 CSR-upload (the last: hipSpMVAutoCSR) + 3 ELL launchers; 5 + 3 OpenMP variants like the reference
     assert "AVG_TIMES_ITERATION:25" in out and "MAX_ROW_NZ" in out and "omp sched gather:" in out
 
 
