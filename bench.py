@@ -595,6 +595,7 @@ def run_single(args, api, synth, torch, w):
         "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": res["workload"]["workload"], **{k: v for k, v in res["workload"].items() if k != "workload"},
                    "kernel": res["launcher"], "auto_candidates_ms": res["auto_candidates_ms"],
+                   "library_auto_choice": res.get("library_auto_choice"),
                    "parallelism": "1 GPU", "libspmvhip_sha256": lib_sha256(api)},
         "hbm_gbps": res["hbm_gbps"], "hbm_roofline_frac": res["hbm_frac"],
         "roofline": {"bound": "hbm", "achieved": res["hbm_gbps"], "peak": HBM_PEAK * 1e-9, "unit": "GB/s",
