@@ -18,14 +18,17 @@
 // HBM sees the 12 B/nnz stream, x once per XCD and round of bins and y once.
 //
 // Measured (profiles/r02_summary.md): c2 0.110 ms = 46 % of the 8 TB/s roofline (two-phase 0.149, SELL 0.237);
-// c3 0.88 ms = 37 % (two-phase 1.03); band +-16 Ki 0.41 ms = 78 % (5.9 TB/s of algorithmic bytes).
-// What bounds it when the columns have no locality is the rate at which a CU's L1 takes lines from L2 -- each
-// gather instruction touches ~47 distinct lines on c3, and 0.27-0.38 lines per clock and CU is what this kernel and
-// scripts/microbench_gather.hip both reach (~64 lines in flight per CU over ~200 clocks) -- not HBM, and not L2
-// misses: see the throttle note below.  For very wide matrices the fabric takes over: every XCD re-reads the lines
-// of x its 32 bins touch in every round of bins (c5: 0.08 entries per line and bin -> 50 B of line fills per
-// entry), so the format pays off while x (N * 8 B) is small against the entry stream -- bench.py tries it while x
-// fits the Infinity Cache; wider matrices are the two-phase kernel's.
+// c3 0.87 ms = 37 % (two-phase 1.03); band +-16 Ki 0.41 ms = 79 % (5.9 TB/s of algorithmic bytes).
+// What bounds it when the columns have no locality is the CU's own L1: a 64-lane gather costs it ~28 clocks plus ~2.2
+// clocks per distinct line it takes from L2 (the 64 B/clock fill path), each gather instruction touches ~47 lines on
+// c3, and that adds up to the kernel time -- the kernel without its LDS adds is no faster, without its gathers it is
+// the 12 B/nnz stream (0.41 ms), a bin takes the same ~415 us whether 64 or 256 CUs are working, and neither the
+// cache-policy bits nor the address form of the gather change anything (DESIGN.md sections 4 and 8,
+// profiles/r02_stripes_*.log).  Not HBM, and not L2 misses: see the throttle note below.  For very wide matrices the
+// fabric takes over: every XCD re-reads the lines of x its 32 bins touch in every round of bins (c5: 0.08 entries
+// per line and bin -> 50 B of line fills per entry), so the format pays off while x (N * 8 B) is small against the
+// entry stream -- bench.py and hipSpMVAutoCSR try it while x fits the Infinity Cache; wider matrices are the
+// two-phase kernel's.
 //
 // Relation to the reference: the computation of cudaSpMVWarpPerRowCSR (src/SpMV_CUDA.cu:52-73) -- lanes
 // multiply entries of coalesced AS/JA spans with gathered x and the partial sums are reduced on chip -- with
