@@ -225,8 +225,13 @@ __device__ __forceinline__ void p1_load(P1Regs& r, uint32_t p, uint32_t ve, cons
 #pragma unroll
     for (int u = 0; u < P1_DEPTH; ++u) {
         const uint32_t q = min(p + u * P1_STEP, ve - 2u);
+#ifdef SPMV_P1_PLAIN_LOAD   // tuning
+        r.a[u] = *(const dbl2*)(val + q);
+        r.c[u] = *(const ush2*)(lcol + q);
+#else
         r.a[u] = __builtin_nontemporal_load((const dbl2*)(val + q));
         r.c[u] = __builtin_nontemporal_load((const ush2*)(lcol + q));
+#endif
     }
 }
 
@@ -330,8 +335,22 @@ __device__ __forceinline__ void p2_fetch(P2Regs& r, P2Cursor& c, uint32_t vbase,
             c.n2 = tl[c.k + 2];
         }
         const uint32_t vc = min(v, we - 1u);
+        // The products are read with the DEFAULT cache policy, not non-temporally: a wavefront's 64 positions are 512
+        // contiguous bytes at an arbitrary offset (a tile starts wherever the slice-major order put it), so consecutive
+        // steps share the line they meet in.  Through L1 the second step hits; a non-temporal load bypasses L1 and the
+        // line, already dropped by L2, comes from HBM a second time -- that was the "run-boundary" traffic of round 1
+        // (phase 2 of c5: 3.19 -> 2.92 ms, the SpMV 8.49 -> 8.15 ms, medians of 6 fresh processes each;
+        // profiles/r02_tiles_load_policy.log).  SPMV_P2_NT_PROD restores the old form for the A/B.
+#ifdef SPMV_P2_NT_PROD
         r.pv[u] = __builtin_nontemporal_load(prod + (uint32_t)(vc + d));
+#else
+        r.pv[u] = prod[(uint32_t)(vc + d)];
+#endif
+#ifdef SPMV_P2_PLAIN_ROW    // tuning
+        const uint16_t row = lrow[vc];
+#else
         const uint16_t row = __builtin_nontemporal_load(lrow + vc);
+#endif
         r.rv[u] = v < we ? row : P2_NONE;
     }
 }
