@@ -139,6 +139,9 @@ def test_mode_strings_are_exact_match():
     assert m("CUDA_CSR_ROWS") == 8 and m("CUDA_CSR_ROWS_WARP") == 9 and m("HIP_CSR_ROWS_WARP") == 9
     assert m("CUDA_ELL_ROWS") == 10 and m("CUDA_ELL_ROWS_WARP_NN_TRANSPOSED") == 12
     assert m("CSR_ROWS") == 1 and m("ELL_TILES") == 7
+    # appended modes keep the reference's values for everything before them (enum order of src/include/SpMV.h:42-59)
+    assert m("CUDA_CSR_TILES") == m("HIP_CSR_TILES") == 14 and m("CUDA_SELL_ROWS") == 15
+    assert m("CUDA_CSR_STRIPES") == m("HIP_CSR_STRIPES") == 16 and m("CUDA_CSR_AUTO") == m("HIP_CSR_AUTO") == 17
     assert m("CUDA_CSR_ROWS_WARPX") == -1 and m("CUDA_CSR") == -1 and m("") == -1   # no prefix matching
 
 
