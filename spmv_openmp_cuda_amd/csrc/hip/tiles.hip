@@ -261,16 +261,24 @@ __global__ __launch_bounds__(PB_THREADS) void pb_expand_kernel(
 
     uint32_t p = vb + 2 * threadIdx.x;
     P1Regs cur, nxt;
-    if (vec) p1_load(cur, p, ve, val, lcol);        // the stream starts moving before the x slice is staged
-
     const uint64_t col0 = (uint64_t)w.x * PB_C;
+    // Order of the first requests: the x slice BEFORE the first stream batch.  vmcnt counts in issue order, so the LDS
+    // fill below waits for the slice only while the batch behind it is still in flight; with the batch first (round 1)
+    // the fill waited for both (c5: 8.13-8.20 against 8.26-8.46 ms over 5 fresh processes each,
+    // profiles/r02_tiles_load_policy.log).  SPMV_P1_STREAM_FIRST restores the old order for the A/B.
     {
         double xv[PB_C / PB_THREADS];
+#ifdef SPMV_P1_STREAM_FIRST
+        if (vec) p1_load(cur, p, ve, val, lcol);
+#endif
 #pragma unroll
         for (uint32_t i = 0; i < PB_C / PB_THREADS; ++i) {
             const uint32_t k = threadIdx.x + i * PB_THREADS;
             xv[i] = (col0 + k < N) ? x[col0 + k] : 0.0;
         }
+#ifndef SPMV_P1_STREAM_FIRST
+        if (vec) p1_load(cur, p, ve, val, lcol);
+#endif
 #pragma unroll
         for (uint32_t i = 0; i < PB_C / PB_THREADS; ++i) xs[threadIdx.x + i * PB_THREADS] = xv[i];
     }
