@@ -620,7 +620,7 @@ struct TempBuf {
 // addresses matters when a matrix is processed as several row groups whose products fit the 256 MiB Infinity
 // Cache: the lines are overwritten while still cached instead of being written back to HBM and re-allocated
 // (scripts/microbench_mall.hip: write-then-read of a 128 MiB buffer 6.6 TB/s, of a 2 GiB one 4.9-5.1 TB/s).
-struct ProdWorkspace { double* p = nullptr; size_t cap = 0; hipEvent_t lastUse = nullptr; hipStream_t lastStream = nullptr; bool used = false; };   // lastStream: where the products were last written or read
+struct ProdWorkspace { double* p = nullptr; void* raw = nullptr; size_t cap = 0; hipEvent_t lastUse = nullptr; hipStream_t lastStream = nullptr; bool used = false; };   // lastStream: where the products were last written or read
 static ProdWorkspace g_prod[16];
 
 static ProdWorkspace* prodSlot() {
@@ -634,9 +634,12 @@ static double* prodWorkspace(size_t n, bool grow) {
     if (!w) return nullptr;
     if (n <= w->cap || !grow) return n <= w->cap ? w->p : nullptr;
     (void)hipDeviceSynchronize();                   // nothing may still read the old buffer
-    if (w->p) (void)hipFree(w->p);
-    w->p = nullptr; w->cap = 0;
-    if (hipMalloc(&w->p, n * sizeof(double)) != hipSuccess) { w->p = nullptr; return nullptr; }
+    if (w->raw) (void)hipFree(w->raw);
+    w->p = nullptr; w->raw = nullptr; w->cap = 0;
+    size_t shift = 0;                               // tuning only: placement of the products relative to the other arrays
+    if (const char* e = getenv("SPMV_PB_PROD_OFFSET")) { const long v = atol(e); if (v >= 0 && v <= (2l << 20) && v % 256 == 0) shift = (size_t)v; }
+    if (hipMalloc(&w->raw, n * sizeof(double) + shift) != hipSuccess) { w->raw = nullptr; return nullptr; }
+    w->p = reinterpret_cast<double*>(static_cast<char*>(w->raw) + shift);
     w->cap = n;
     return w->p;
 }
@@ -665,7 +668,7 @@ void freeTilesWorkspace() {
     for (int d = 0; d < 16; ++d)
         if (g_prod[d].p || g_prod[d].lastUse) {
             (void)hipSetDevice(d);
-            if (g_prod[d].p) (void)hipFree(g_prod[d].p);
+            if (g_prod[d].raw) (void)hipFree(g_prod[d].raw);
             if (g_prod[d].lastUse) (void)hipEventDestroy(g_prod[d].lastUse);
             g_prod[d] = ProdWorkspace{};
         }
@@ -763,6 +766,8 @@ int buildTiles(DevMat* d, const spmvTilesOpts* opts) {
         hipMalloc(&t->waveTile, (size_t)t->B * P2_WAVES * 4))
         return fail("format allocation");
     t->allocMs = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - allocT0).count();
+    if (getenv("SPMV_PB_DEBUG_ADDR"))               // tuning only
+        fprintf(stderr, "libspmvhip: tiles: val %p lcol %p lrow %p prod %p\n", (void*)t->val, (void*)t->lcol, (void*)t->lrow, (void*)prodWorkspace(nnz, false));
 
     if (d->irpBytes == 4)
         hipLaunchKernelGGL((pb_payload_kernel<uint32_t>), grid2d((M + 3) / 4, 256), dim3(256), 0, nullptr, M, static_cast<const uint32_t*>(d->IRP), d->JA, d->AS,
