@@ -35,6 +35,9 @@ int spmvHipDeviceCount(void);
 /* Stream (hipStream_t passed as void*) used by all later launches/copies of the
  * calling process; NULL = the default stream. */
 int spmvHipSetStream(void* stream);
+/* (With spmvHipSetSync(0) a launcher whose format exists only enqueues kernels on this stream -- no event, allocation or
+ * synchronisation -- so a solver's inner loop can be captured into a HIP graph and replayed:
+ * tests/test_gpu_parity.py::test_launchers_capture_into_a_hip_graph.) */
 /* sync != 0 (default): every SpMV launcher waits for completion before it
  * returns and stores the device time in `ElapsedInternal`-style seconds
  * retrievable with spmvHipLastKernelSeconds() -- the behaviour of the

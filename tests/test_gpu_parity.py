@@ -608,6 +608,51 @@ def test_auto_launcher_picks_and_remembers(api, oracle):
     de.free()
 
 
+def test_launchers_capture_into_a_hip_graph(api, oracle):
+    """With spmvHipSetSync(0) a launcher only enqueues kernels on the library stream -- no event, no allocation, no
+    synchronisation once its format exists -- so a solver's inner loop can be captured into a HIP graph (torch's
+    CUDAGraph on ROCm) and replayed.  Captured: all five CSR launchers, one after the other; nothing runs at capture
+    time; one replay computes all five y."""
+    import ctypes as C
+    torch = pytest.importorskip("torch")
+    M, N, IRP, JA, AS = CASES["irregular"]
+    x_host = _x(np.random.default_rng(41), N)
+    y_ref = oracle.csr_serial(IRP, JA, AS, x_host)
+    dmat = api.spMatCpyCSR(api.HostCSR(M, N, IRP, JA, AS))
+    names = ["hipSpMVRowsCSR", "hipSpMVWarpPerRowCSR", "hipSpMVTilesCSR", "hipSpMVStripesCSR", "hipSpMVRowsSELL"]
+    cfg = api.CONFIG()
+    stream = torch.cuda.Stream()
+    try:
+        with torch.cuda.stream(stream):
+            x = torch.from_numpy(x_host).cuda()
+            ys = [torch.full((M,), float("nan"), dtype=torch.float64, device="cuda") for _ in names]
+            api.lib.spmvHipSetStream(C.c_void_p(stream.cuda_stream))
+            api.lib.spmvHipSetSync(0)
+            for n, y in zip(names, ys):                      # first calls build the private formats: not capturable
+                assert api.SPMV_LAUNCHERS[n](C.byref(dmat.handle), x.data_ptr(), cfg, y.data_ptr()) == 0
+            torch.cuda.synchronize()
+            for y in ys:
+                y.fill_(float("nan"))
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph, stream=stream):
+                for n, y in zip(names, ys):
+                    assert api.SPMV_LAUNCHERS[n](C.byref(dmat.handle), x.data_ptr(), cfg, y.data_ptr()) == 0
+            torch.cuda.synchronize()
+            assert all(bool(torch.isnan(y).all()) for y in ys)            # capture ran nothing
+            for _ in range(2):
+                graph.replay()
+            torch.cuda.synchronize()
+            for n, y in zip(names, ys):
+                yh = y.cpu().numpy()
+                assert not np.isnan(yh).any(), n
+                assert tight_error(IRP, JA, AS, x_host, y_ref, yh) <= TIGHT, n
+            assert np.array_equal(ys[0].cpu().numpy(), y_ref)
+    finally:
+        api.lib.spmvHipSetStream(None)
+        api.lib.spmvHipSetSync(1)
+        dmat.free()
+
+
 def _fuzz_case(seed):
     """Seeded random shape: 1..4000 rows, 1..200 000 columns, row lengths from a mix of laws (many empty rows, a
     geometric body, a few rows as long as the matrix allows), sorted distinct columns."""
