@@ -23,6 +23,10 @@
 //     that a lane fetches 4 columns with one 16-byte load and 4 values with two: 7 instead of 12 vector-memory
 //     instructions per 4 entries, bit-identical, c2 0.244 ms against 0.238.  The coalesced loads are not what the L1
 //     spends its time on; the 64-line gathers are;)
+//   * (tried and removed, round 2: eight slices per wavefront with the loop over the slots outside the loop over the
+//     slices, so that the whole launch walks slot 0, 1, 2, ... -- i.e. ascending columns -- together and gathers from one
+//     moving window of x: c2 0.225 ms against 0.238, but 4.2 vs 3.8 ms on c3 and 2.5-2.7 vs 1.3-1.6 ms on the banded
+//     matrices, whose locality lives inside a slice; profiles/r02_sell_sweep.log;)
 //   * rows longer than SELL_MAX_ROW do not enter the slices (one of them would pin a wavefront for
 //     a whole slice): they are processed workgroup-per-row from the CSR arrays (shuffle tree).
 #include <hip/hip_runtime.h>
