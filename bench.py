@@ -718,9 +718,11 @@ def run_multi(args, api, synth, torch, dist, w, world, rank, local):
             torch.cuda.synchronize()
 
         def step(self, ev=None):
-            for g, run in enumerate(self.runs):
-                run.enqueue(ev[g] if ev else None)
-            px.finish()
+            try:
+                for g, run in enumerate(self.runs):
+                    run.enqueue(ev[g] if ev else None)
+            finally:
+                px.finish()                          # also when a launcher failed here: the other ranks are in this barrier
             return self.y
 
         def sync(self):
@@ -911,11 +913,47 @@ def run_multi(args, api, synth, torch, dist, w, world, rank, local):
         px.close()
 
 
+def spawn_ranks(world):
+    """`python bench.py --gpus N` with no launcher around it: start N fresh rank processes (torch.distributed.run on the
+    loopback address) and relay rank 0's JSON line and the job's exit code.  Runs before torch or the HIP library are
+    imported -- this parent never touches a GPU and never replaces itself with another program."""
+    import socket
+    import subprocess
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")        # dmabuf IPC: RCCL and the peer windows need it on this driver
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, text=True)
+    out, _ = proc.communicate()
+    lines = []
+    for raw in out.splitlines():
+        try:
+            if "metric" in json.loads(raw):
+                lines.append(raw)
+                continue
+        except ValueError:
+            pass
+        if raw.strip():
+            print(raw, file=sys.stderr)                      # anything else a rank wrote to stdout is not the result line
+    if lines:
+        sys.stdout.write(lines[-1] + "\n")
+        sys.stdout.flush()
+    if proc.returncode == 0 and not lines:
+        print("[bench] the ranks ended without a result line", file=sys.stderr)
+        return 1
+    return proc.returncode
+
+
 def main():
     global _REAL_STDOUT
     args = parse()
     world = args.gpus
     multi = world > 1 or args.force_dist
+    if world > 1 and ("RANK" not in os.environ or "WORLD_SIZE" not in os.environ):
+        sys.exit(spawn_ranks(world))
     if multi:
         # RCCL prints a version banner on fd 1 when the communicator comes up; the contract is ONE JSON
         # line on stdout, so everything else of this process is sent to stderr
@@ -932,7 +970,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if multi:
-        assert int(os.environ.get("WORLD_SIZE", "1")) == world, "launch with torch.distributed.run --nproc-per-node N"
+        if int(os.environ.get("WORLD_SIZE", "1")) != world:
+            raise SystemExit(f"--gpus {world} but the launcher started WORLD_SIZE={os.environ.get('WORLD_SIZE')} ranks")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29531")
         os.environ.setdefault("RANK", "0")
@@ -952,6 +991,10 @@ def main():
     api.spmvHipInit(local)
     api.lib.spmvHipSetStream(C.c_void_p(torch.cuda.current_stream().cuda_stream))
     api.lib.spmvHipSetSync(0)
+    # this program compares the library's kernels by NAME itself: "hipSpMVWarpPerRowCSR" here is the LDS-stream kernel
+    # (variant 1), not the default variant 2 that picks among them -- what that default picks is reported per block as
+    # `library_auto_choice`
+    api.set_variant("hipSpMVWarpPerRowCSR", 1)
     if args.variant >= 0 and args.launcher != "auto":
         api.set_variant(args.launcher, args.variant)
     w = synth.WORKLOADS[args.workload]

@@ -140,6 +140,28 @@ size_t spmvHipStripesBytes(spmat* dMat);
 /* shape of the built format (zeros before the build): bins, rows of the highest bin, 1 if the 14 B/nnz
  * encoding with 32-bit columns had to be used, device time of the one-time build in ms */
 int    spmvHipStripesShape(spmat* dMat, unsigned* nBins, unsigned* rowsPerBin, int* wide, double* buildMs);
+/* Build options of the stripes format (all zero / -1 = automatic).  Arguments of the build, not process state:
+ * spmvHipBuildStripesOpt(dMat, &opts) builds -- or REbuilds -- the format of this handle with them.
+ *   rowsPerBin     0 or 1..20000: upper bound of the rows of a bin (y of a bin lives in LDS).
+ *   grid           0 or 1..CUs of the device: persistent workgroups that walk the bins (the bin count is made a
+ *                  multiple of it); fewer than the CU count leaves CUs to a kernel running beside this one.
+ *   spread         -1 or 0..1024: 1/1024ths of a bin over which the column sweeps of one XCD's workgroups start
+ *                  (default 6; ignored by the deterministic form).
+ *   wide           1: force the 14 B/nnz encoding with 32-bit columns; 0 / -1: only when a step spans >= 2^17 columns.
+ *   deterministic  1: every row is added by ONE wavefront in ascending column order (local row mod 4 owns it), so the
+ *                  result is the same bits in every run, on any number of row shards, and -- the products being rounded
+ *                  before they are added -- the bits of the serial oracle (sgemvSerial, src/SpMV_CSR_OMP.c:229-250) when
+ *                  the columns of every row ascend, as the reference's loader guarantees (src/lib/parser.c:195-202).
+ *                  Costs time: a gather covers neighbours of a quarter of the bin's entries. */
+typedef struct { unsigned rowsPerBin; unsigned grid; int spread; int wide; int deterministic; } spmvStripesOpts;
+int spmvHipBuildStripesOpt(spmat* dMat, const spmvStripesOpts* opts);
+typedef struct {
+    unsigned nBins, rowsPerBin, grid, spread;
+    int      wide, deterministic;
+    double   buildMs;          /* device time of the one-time build */
+    size_t   bytes;            /* device memory of the format */
+} spmvStripesInfo;
+int spmvHipStripesInfo(spmat* dMat, spmvStripesInfo* info);   /* zeros when the format has not been built */
 
 /* The fastest CSR launcher for THIS matrix, chosen by measurement at the first call for a handle (the reference's
  * callers choose a kernel by name -- CUDA_CSR_ROWS_WARP, ... -- src/main.cu:103-139; which of this library's kernels
@@ -167,6 +189,9 @@ size_t spmvHipSellBytes(spmat* dMat);
  * bracket, no synchronisation): warpPerRow = 0 -> hipSpMVRowsCSR semantics,
  * != 0 -> hipSpMVWarpPerRowCSR.  The current device must be the matrix'. */
 int spmvHipEnqueueCSR(spmat* dMat, int warpPerRow, double* dX, double* dY, void* stream);
+/* The same for the launcher hipSpMVAutoCSR / hipSpMVWarpPerRowCSR (variant 2) chose for this handle; the FIRST call for a
+ * handle measures the candidates on `stream` and synchronises it (later calls only enqueue). */
+int spmvHipEnqueueAuto(spmat* dMat, double* dX, double* dY, void* stream);
 
 /* Kernel variants behind each launcher (for A/B measurement; default = best):
  *   hipSpMVRowsCSR        0 = one thread walks its row in global memory: the plain restatement of
@@ -175,8 +200,19 @@ int spmvHipEnqueueCSR(spmat* dMat, int warpPerRow, double* dX, double* dY, void*
  *                             thread sums its row in ascending-j order (bit-identical to the serial oracle)
  *   hipSpMVWarpPerRowCSR  0 = one wavefront per row, __shfl_down tree (the reference kernel's intent, for
  *                             every row)
- *                         1 = (default) LDS-stream kernel with the LDS segmented reduction for short rows and
+ *                         1 = LDS-stream kernel with the LDS segmented reduction for short rows and
  *                             wavefront-/workgroup-per-row sums for long ones
+ *                         2 = (default) the fastest of this library's reduction-order kernels for THIS matrix --
+ *                             variant 1, hipSpMVTilesCSR, hipSpMVStripesCSR -- chosen exactly as hipSpMVAutoCSR does:
+ *                             the FIRST call for a handle runs the eligible candidates on the caller's x (each leaves
+ *                             the complete y; matrices below 2^18 entries go straight to variant 1), keeps the
+ *                             fastest and frees the others' formats.  Cost of that first call: a handful of SpMVs
+ *                             plus the format builds (c3: ~0.15 s; c5: ~1-2 s, mostly allocation) and it synchronises
+ *                             the stream; afterwards +12 B/nnz of device memory for the winner's copy of the matrix
+ *                             (+ the shared 8 B/nnz product workspace when the two-phase kernel wins).  This is what
+ *                             the reference's names reach: SpmvCUDA_CSRFuncs[SpmvCUDA_CSRFuncs_WarpPerRowIdx],
+ *                             CUDA_CSR_ROWS_WARP, spmvHipWarpPerRowCSR (src/include/SpMV.h:130-134).  A caller that
+ *                             wants the one-kernel behaviour of round 1/2 sets variant 1 (CLI: SPMV_VARIANT=1).
  * Returns EXIT_FAILURE for an unknown (launcher, variant). */
 int spmvHipSetVariant(const char* launcher, int variant);
 /* Use the RL array for ELL early exit (1, default when RL was uploaded) or walk
@@ -218,6 +254,12 @@ int spmvHipCompactRows(double* dY, const double* dYPad, const ulong* bounds, int
  * an RCCL all-gather over xGMI.  bench.py uses one process per GPU instead and
  * calls the single-device entry points + torch.distributed (RCCL). */
 int spmvHipShardCSR(spmat* host, int nDev, void** shardHandle);
+/* ... with every device's rows cut into `groups` consecutive row groups (0 = automatic: 2 when nDev > 1): the
+ * all-gather of group g runs on its own stream while group g+1 is computed. */
+int spmvHipShardCSRGroups(spmat* host, int nDev, int groups, void** shardHandle);
+/* mode 0: the kernel of hipSpMVRowsCSR (serial order: y bit-identical to the 1-GPU result); mode != 0: that of
+ * hipSpMVWarpPerRowCSR (variant 2: the fastest reduction-order kernel per block, chosen by an untimed pass at the first
+ * call).  kernelSec = kernels of all row groups, slowest device; gatherSec = what the exchange adds after overlap. */
 int spmvHipSpMVSharded(void* shardHandle, const double* hX, int mode, double* hY,
                        double* kernelSec, double* gatherSec);
 int spmvHipShardFree(void* shardHandle);

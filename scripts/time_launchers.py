@@ -1,6 +1,9 @@
 #!/usr/bin/env python3
 """Kernel time (HIP events) of several launchers on one synthetic workload, same matrix, same x:
     python3 scripts/time_launchers.py c3 hipSpMVTilesCSR hipSpMVStripesCSR [--steps 20] [--check]
+A launcher may also be named the reference's way (CUDA_CSR_ROWS, CUDA_CSR_ROWS_WARP: what the CLI and the function
+tables resolve those names to, default variants) or carry a suffix: hipSpMVWarpPerRowCSR:1 (kernel variant),
+hipSpMVStripesCSR:det / hipSpMVTilesCSR:det (the deterministic form of the format is built first).
 --check compares head / middle / tail 200 k-row windows of every launcher's y with the serial oracle."""
 import argparse
 import ctypes as C
@@ -40,18 +43,34 @@ def main():
     alg = synth.algorithmic_bytes_csr(nnz, w.N, w.N)
     cfg = api.CONFIG()
     windows = None
-    for name in a.launchers:
+    modes = {"CUDA_CSR_ROWS": "hipSpMVRowsCSR", "CUDA_CSR_ROWS_WARP": "hipSpMVWarpPerRowCSR"}
+    for spec in a.launchers:
+        name, _, suffix = modes.get(spec, spec).partition(":")
         fn = api.SPMV_LAUNCHERS[name]
+        api.set_variant("hipSpMVRowsCSR", 1)
+        api.set_variant("hipSpMVWarpPerRowCSR", 2)
+        if suffix.isdigit():
+            api.set_variant(name, int(suffix))
+        elif suffix == "det" and name == "hipSpMVStripesCSR":
+            api.build_stripes(dm, deterministic=True)
+        elif suffix == "det" and name == "hipSpMVTilesCSR":
+            api.build_tiles(dm, deterministic=True)
+        elif suffix == "" and name == "hipSpMVStripesCSR" and api.stripes_info(dm).deterministic:
+            api.build_stripes(dm)
+        elif suffix == "" and name == "hipSpMVTilesCSR" and api.tiles_info(dm).nBins and getattr(api.tiles_info(dm), "deterministic", 0):
+            api.build_tiles(dm)
         y.fill_(float("nan"))
         if fn(C.byref(dm.handle), x.data_ptr(), cfg, y.data_ptr()):
-            print(f"{w.name} {name}: FAILED")
+            print(f"{w.name} {spec}: FAILED")
             continue
         torch.cuda.synchronize()
         extra = ""
         if name == "hipSpMVStripesCSR":
-            nb, rpb, wide, ms = C.c_uint(), C.c_uint(), C.c_int(), C.c_double()
-            api.lib.spmvHipStripesShape(C.byref(dm.handle), C.byref(nb), C.byref(rpb), C.byref(wide), C.byref(ms))
-            extra = f" bins={nb.value} rows/bin<={rpb.value} wide={wide.value} build={ms.value:.1f}ms"
+            i = api.stripes_info(dm)
+            extra = f" bins={i.nBins} rows/bin<={i.rowsPerBin} wide={i.wide} det={i.deterministic} build={i.buildMs:.1f}ms"
+        if name in ("hipSpMVWarpPerRowCSR", "hipSpMVAutoCSR"):
+            pick = api.lib.spmvHipAutoChoice(C.byref(dm.handle), None)
+            extra = f" pick={pick.decode() if pick else None}"
         if a.check:
             if windows is None:
                 windows = bench.OracleWindows(synth, w, irp, x_host, lens)
@@ -76,7 +95,7 @@ def main():
         avg = sum(ms) / len(ms)
         if os.environ.get("SPMV_PRINT_STEPS"):
             print("steps ms:", " ".join(f"{t:.3f}" for t in ms))
-        print(f"{w.name} {name}: avg {avg:.4f} ms  min {min(ms):.4f}  max {max(ms):.4f}  = {alg / avg / 8e9 * 100:.1f}% of 8 TB/s "
+        print(f"{w.name} {spec}: avg {avg:.4f} ms  min {min(ms):.4f}  max {max(ms):.4f}  = {alg / avg / 8e9 * 100:.1f}% of 8 TB/s "
               f"({2 * nnz / avg * 1e-6:.0f} GFLOP/s){extra}", flush=True)
     dm.free()
     api.spmvHipFinalize()

@@ -62,6 +62,12 @@ _sigs = {
     "spmvHipStripesBytes": ([C.POINTER(spmat)], _sz),
     "spmvHipStripesShape": ([C.POINTER(spmat), C.POINTER(C.c_uint), C.POINTER(C.c_uint), C.POINTER(_i), C.POINTER(C.c_double)], _i),
     "spmvHipEnqueueCSR": ([C.POINTER(spmat), _i, _vp, _vp, _vp], _i),
+    "spmvHipEnqueueAuto": ([C.POINTER(spmat), _vp, _vp, _vp], _i),
+    "spmvHipBuildStripesOpt": ([C.POINTER(spmat), _vp], _i), "spmvHipStripesInfo": ([C.POINTER(spmat), _vp], _i),
+    "spmvHipShardCSR": ([C.POINTER(spmat), _i, C.POINTER(_vp)], _i),
+    "spmvHipShardCSRGroups": ([C.POINTER(spmat), _i, _i, C.POINTER(_vp)], _i),
+    "spmvHipSpMVSharded": ([_vp, _vp, _i, _vp, C.POINTER(C.c_double), C.POINTER(C.c_double)], _i),
+    "spmvHipShardFree": ([_vp], _i),
     "hipSpMVRowsELL": (_SPMV_ARGS, _i), "hipSpMVRowsELLNNTransposed": (_SPMV_ARGS, _i),
     "hipSpMVWarpsPerRowELLNTrasposed": (_SPMV_ARGS, _i),
     "spmvHipSetVariant": ([C.c_char_p, _i], _i), "spmvHipSetEllRowLens": ([_i], _i),
@@ -100,6 +106,19 @@ class spmvTilesOpts(C.Structure):
 class spmvTilesInfo(C.Structure):
     _fields_ = [("nBins", C.c_uint), ("rowsPerBin", C.c_uint), ("nSlices", C.c_uint), ("taper", _i), ("ntStore", _i),
                 ("chunk", C.c_uint), ("buildMs", C.c_double), ("bytes", _sz), ("allocMs", C.c_double)]
+
+
+class spmvStripesOpts(C.Structure):
+    """include/spmvHip.h `spmvStripesOpts` (0 / 0 / -1 / -1 / 0 = automatic)."""
+    _fields_ = [("rowsPerBin", C.c_uint), ("grid", C.c_uint), ("spread", _i), ("wide", _i), ("deterministic", _i)]
+
+    def __init__(self, rowsPerBin=0, grid=0, spread=-1, wide=-1, deterministic=0):
+        super().__init__(rowsPerBin, grid, spread, wide, deterministic)
+
+
+class spmvStripesInfo(C.Structure):
+    _fields_ = [("nBins", C.c_uint), ("rowsPerBin", C.c_uint), ("grid", C.c_uint), ("spread", C.c_uint), ("wide", _i),
+                ("deterministic", _i), ("buildMs", C.c_double), ("bytes", _sz)]
 
 
 IPC_HANDLE_BYTES = 64
@@ -367,6 +386,18 @@ def build_tiles(dmat: DeviceMatrix, rowsPerBin=0, taper=False, ntStore=-1, chunk
 def tiles_info(dmat: DeviceMatrix) -> spmvTilesInfo:
     info = spmvTilesInfo()
     _check(lib.spmvHipTilesInfo(C.byref(dmat.handle), C.byref(info)), "spmvHipTilesInfo")
+    return info
+
+
+def build_stripes(dmat: DeviceMatrix, rowsPerBin=0, grid=0, spread=-1, wide=-1, deterministic=False):
+    """spmvHipBuildStripesOpt: (re)build the stripes format of this handle with explicit options."""
+    o = spmvStripesOpts(int(rowsPerBin), int(grid), int(spread), int(wide), 1 if deterministic else 0)
+    _check(lib.spmvHipBuildStripesOpt(C.byref(dmat.handle), C.byref(o)), "spmvHipBuildStripesOpt")
+
+
+def stripes_info(dmat: DeviceMatrix) -> spmvStripesInfo:
+    info = spmvStripesInfo()
+    _check(lib.spmvHipStripesInfo(C.byref(dmat.handle), C.byref(info)), "spmvHipStripesInfo")
     return info
 
 

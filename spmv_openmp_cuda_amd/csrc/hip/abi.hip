@@ -21,7 +21,8 @@ struct State {
     hipStream_t stream = nullptr;
     bool        sync = true;
     int         variantRowsCSR = 1;     // 0 scalar restatement, 1 LDS-stream kernel (sequential row sums)
-    int         variantWarpCSR = 1;     // 0 wavefront-per-row restatement, 1 LDS-stream kernel (LDS segmented reduction)
+    int         variantWarpCSR = 2;     // 0 wavefront-per-row restatement, 1 LDS-stream kernel (LDS segmented reduction), 2 the fastest
+                                        // reduction-order kernel for the matrix (LDS-stream / two-phase / stripes), measured at first use
     bool        ellRowLens = true;
     double      lastSeconds = 0;
     spmvDim3    lastGrid{0, 0, 0}, lastBlock{0, 0, 0};
@@ -122,6 +123,7 @@ struct Launch {
         S.lastBlock = {block.x, block.y, block.z};
         if (timed) (void)hipEventRecord(S.ev0, S.stream);
     }
+    void shape(dim3 grid, dim3 block) { S.lastGrid = {grid.x, grid.y, grid.z}; S.lastBlock = {block.x, block.y, block.z}; }
     int finish(const char* who) {
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) { ERR("%s: launch failed: %s", who, hipGetErrorString(e)); return EXIT_FAILURE; }
@@ -135,6 +137,17 @@ struct Launch {
         return EXIT_SUCCESS;
     }
 };
+
+// a launcher call that has nothing to launch (no rows, or no entries: y = 0): no stale time or shape is left behind
+int nothingToLaunch(DevMat* d, double* dY) {
+    S.lastSeconds = 0;
+    S.lastGrid = {0, 0, 0}; S.lastBlock = {0, 0, 0};
+    if (d->M && dY) {
+        HIP_TRY(hipMemsetAsync(dY, 0, d->M * sizeof(double), S.stream));
+        if (S.sync) HIP_TRY(hipStreamSynchronize(S.stream));
+    }
+    return EXIT_SUCCESS;
+}
 
 unsigned blockThreads(const CONFIG& cfg, unsigned dflt, unsigned maxThreads) {
     unsigned t = cfg.blockSize.x * std::max(1u, cfg.blockSize.y) * std::max(1u, cfg.blockSize.z);
@@ -369,7 +382,7 @@ int spmvHipDeviceSynchronize(void) { HIP_TRY(hipDeviceSynchronize()); return EXI
 int spmvHipSetVariant(const char* launcher, int variant) {
     if (!launcher) return EXIT_FAILURE;
     if (!strcmp(launcher, "hipSpMVRowsCSR") && variant >= 0 && variant <= 1) { S.variantRowsCSR = variant; return EXIT_SUCCESS; }
-    if (!strcmp(launcher, "hipSpMVWarpPerRowCSR") && variant >= 0 && variant <= 1) { S.variantWarpCSR = variant; return EXIT_SUCCESS; }
+    if (!strcmp(launcher, "hipSpMVWarpPerRowCSR") && variant >= 0 && variant <= 2) { S.variantWarpCSR = variant; return EXIT_SUCCESS; }
     ERR("spmvHipSetVariant: unknown (%s, %d)", launcher, variant);
     return EXIT_FAILURE;
 }
@@ -488,8 +501,11 @@ int spmvHipCsrToEll(spmat* dCsr, int transposed, spmat* dEll) {
         size_t freeB = 0, totalB = 0;
         const unsigned __int128 need128 = (unsigned __int128)(transposed ? K : rows) * d->pitch * 12 + (unsigned __int128)rows * 4;
         const size_t need = need128 > (unsigned __int128)~(size_t)0 ? ~(size_t)0 : (size_t)need128;
-        if (hipMemGetInfo(&freeB, &totalB) != hipSuccess) freeB = totalB = 0;
-        if (need > freeB) {
+        // best effort: what is free at this moment (other processes and cached pools count as used); when the query itself
+        // fails the guard is skipped and hipMalloc decides
+        const bool known = hipMemGetInfo(&freeB, &totalB) == hipSuccess;
+        if (!known) (void)hipGetLastError();
+        if (known && need > freeB) {
             ERR("spmvHipCsrToEll: ELL copy of %lu rows x %lu slots needs %.1f GB, device has %.1f GB free: refused "
                 "(the reference refuses above 6*2^27 padded cells, parser.c:223-232)", (unsigned long)rows, (unsigned long)K,
                 (double)need * 1e-9, (double)freeB * 1e-9);
@@ -541,7 +557,7 @@ int hipSpMVRowsCSR(spmat* dMat, double* dX, CONFIG cfg, double* dY) {
     DevMat* d = descOf(dMat, "hipSpMVRowsCSR");
     if (!d) return EXIT_FAILURE;
     if (d->kind != Kind::CSR) { ERR("hipSpMVRowsCSR: handle is not CSR"); return EXIT_FAILURE; }
-    if (d->M == 0) return EXIT_SUCCESS;
+    if (d->M == 0) return nothingToLaunch(d, nullptr);
     if (S.variantRowsCSR == 0) {
         const unsigned bt = blockThreads(cfg, BLOCKS_1D, 1024);
         const dim3 grid = grid2d((d->M + bt - 1) / bt, bt), block(bt);
@@ -556,23 +572,34 @@ int hipSpMVRowsCSR(spmat* dMat, double* dX, CONFIG cfg, double* dY) {
     return L.finish("hipSpMVRowsCSR");
 }
 
-int hipSpMVWarpPerRowCSR(spmat* dMat, double* dX, CONFIG cfg, double* dY) {
+// the LDS-stream kernel with the LDS segmented reduction (variant 1 of hipSpMVWarpPerRowCSR; candidate 0 of the selection)
+static int warpStreamCSR(spmat* dMat, double* dX, CONFIG cfg, double* dY) {
+    (void)cfg;
     DevMat* d = descOf(dMat, "hipSpMVWarpPerRowCSR");
     if (!d) return EXIT_FAILURE;
     if (d->kind != Kind::CSR) { ERR("hipSpMVWarpPerRowCSR: handle is not CSR"); return EXIT_FAILURE; }
-    if (d->M == 0) return EXIT_SUCCESS;
-    if (S.variantWarpCSR == 0) {
-        const unsigned bt = blockThreads(cfg, WAVESIZE * BLOCKS_2D_WARP_R, 1024);
-        const unsigned rowsPerWg = bt / WAVE;
-        const dim3 grid = grid2d((d->M + rowsPerWg - 1) / rowsPerWg, bt), block(bt);
-        Launch L(grid, block);
-        const uint32_t M = (uint32_t)d->M;
-        if (d->irpBytes == 4) hipLaunchKernelGGL((csr_vector_kernel<uint32_t>), grid, block, 0, S.stream, M, static_cast<const uint32_t*>(d->IRP), d->JA, d->AS, dX, dY);
-        else                  hipLaunchKernelGGL((csr_vector_kernel<uint64_t>), grid, block, 0, S.stream, M, static_cast<const uint64_t*>(d->IRP), d->JA, d->AS, dX, dY);
-        return L.finish("hipSpMVWarpPerRowCSR");
-    }
+    if (d->M == 0) return nothingToLaunch(d, nullptr);
     Launch L(grid2d(d->nBlk2, WG_THREADS), dim3(WG_THREADS));
     launchStream2<false>(d, dX, dY);
+    return L.finish("hipSpMVWarpPerRowCSR");
+}
+
+static int autoRun(spmat* dMat, double* dX, CONFIG cfg, double* dY, const char* who);
+
+int hipSpMVWarpPerRowCSR(spmat* dMat, double* dX, CONFIG cfg, double* dY) {
+    if (S.variantWarpCSR == 2) return autoRun(dMat, dX, cfg, dY, "hipSpMVWarpPerRowCSR");
+    if (S.variantWarpCSR == 1) return warpStreamCSR(dMat, dX, cfg, dY);
+    DevMat* d = descOf(dMat, "hipSpMVWarpPerRowCSR");
+    if (!d) return EXIT_FAILURE;
+    if (d->kind != Kind::CSR) { ERR("hipSpMVWarpPerRowCSR: handle is not CSR"); return EXIT_FAILURE; }
+    if (d->M == 0) return nothingToLaunch(d, nullptr);
+    const unsigned bt = blockThreads(cfg, WAVESIZE * BLOCKS_2D_WARP_R, 1024);
+    const unsigned rowsPerWg = bt / WAVE;
+    const dim3 grid = grid2d((d->M + rowsPerWg - 1) / rowsPerWg, bt), block(bt);
+    Launch L(grid, block);
+    const uint32_t M = (uint32_t)d->M;
+    if (d->irpBytes == 4) hipLaunchKernelGGL((csr_vector_kernel<uint32_t>), grid, block, 0, S.stream, M, static_cast<const uint32_t*>(d->IRP), d->JA, d->AS, dX, dY);
+    else                  hipLaunchKernelGGL((csr_vector_kernel<uint64_t>), grid, block, 0, S.stream, M, static_cast<const uint64_t*>(d->IRP), d->JA, d->AS, dX, dY);
     return L.finish("hipSpMVWarpPerRowCSR");
 }
 
@@ -602,7 +629,7 @@ int hipSpMVRowsSELL(spmat* dMat, double* dX, CONFIG cfg, double* dY) {
     DevMat* d = descOf(dMat, "hipSpMVRowsSELL");
     if (!d) return EXIT_FAILURE;
     if (d->kind != Kind::CSR) { ERR("hipSpMVRowsSELL: handle is not CSR (the SELL-C-sigma copy is derived from an uploaded CSR)"); return EXIT_FAILURE; }
-    if (d->M == 0) return EXIT_SUCCESS;
+    if (d->M == 0) return nothingToLaunch(d, nullptr);
     if (!d->sell && buildSell(d)) return EXIT_FAILURE;
     Launch L(grid2d((d->M + 255) / 256, 256), dim3(256));
     if (enqueueSell(d, dX, dY, S.stream)) { ERR("hipSpMVRowsSELL: launch failed"); return EXIT_FAILURE; }
@@ -615,17 +642,29 @@ int spmvHipBuildStripes(spmat* dMat) {
     if (d->kind != Kind::CSR) { ERR("spmvHipBuildStripes: handle is not CSR"); return EXIT_FAILURE; }
     return buildStripes(d);
 }
+int spmvHipBuildStripesOpt(spmat* dMat, const spmvStripesOpts* opts) {
+    DevMat* d = descOf(dMat, "spmvHipBuildStripesOpt");
+    if (!d || !opts) return EXIT_FAILURE;
+    if (d->kind != Kind::CSR || d->M == 0 || d->NZ == 0) { ERR("spmvHipBuildStripesOpt: needs a non-empty CSR handle"); return EXIT_FAILURE; }
+    return buildStripes(d, opts);
+}
 size_t spmvHipStripesBytes(spmat* dMat) {
     DevMat* d = descOf(dMat, "spmvHipStripesBytes");
     return d ? stripesBytes(d) : 0;
 }
+int spmvHipStripesInfo(spmat* dMat, spmvStripesInfo* info) {
+    DevMat* d = descOf(dMat, "spmvHipStripesInfo");
+    if (!d || !info) return EXIT_FAILURE;
+    stripesInfo(d, info);
+    return EXIT_SUCCESS;
+}
 int spmvHipStripesShape(spmat* dMat, unsigned* nBins, unsigned* rowsPerBin, int* wide, double* buildMs) {
-    DevMat* d = descOf(dMat, "spmvHipStripesShape");
-    if (!d) return EXIT_FAILURE;
-    uint32_t b = 0, r = 0;
-    stripesShape(d, &b, &r, wide, buildMs);
-    if (nBins) *nBins = b;
-    if (rowsPerBin) *rowsPerBin = r;
+    spmvStripesInfo i;
+    if (spmvHipStripesInfo(dMat, &i)) return EXIT_FAILURE;
+    if (nBins) *nBins = i.nBins;
+    if (rowsPerBin) *rowsPerBin = i.rowsPerBin;
+    if (wide) *wide = i.wide;
+    if (buildMs) *buildMs = i.buildMs;
     return EXIT_SUCCESS;
 }
 int hipSpMVStripesCSR(spmat* dMat, double* dX, CONFIG cfg, double* dY) {
@@ -633,17 +672,12 @@ int hipSpMVStripesCSR(spmat* dMat, double* dX, CONFIG cfg, double* dY) {
     DevMat* d = descOf(dMat, "hipSpMVStripesCSR");
     if (!d) return EXIT_FAILURE;
     if (d->kind != Kind::CSR) { ERR("hipSpMVStripesCSR: handle is not CSR"); return EXIT_FAILURE; }
-    if (d->M == 0) return EXIT_SUCCESS;
-    if (d->NZ == 0) {                               // nothing to sweep: y = 0
-        HIP_TRY(hipMemsetAsync(dY, 0, d->M * sizeof(double), S.stream));
-        if (S.sync) HIP_TRY(hipStreamSynchronize(S.stream));
-        return EXIT_SUCCESS;
-    }
+    if (d->M == 0 || d->NZ == 0) return nothingToLaunch(d, dY);         // nothing to sweep: y = 0
     if (!d->stripes && buildStripes(d)) return EXIT_FAILURE;
-    uint32_t bins = 0, rowsPerBin = 0;
-    stripesShape(d, &bins, &rowsPerBin, nullptr, nullptr);
-    Launch L(dim3(bins), dim3(1024));
-    if (enqueueStripes(d, dX, dY, S.stream)) { ERR("hipSpMVStripesCSR: launch failed"); return EXIT_FAILURE; }
+    Launch L(dim3(1), dim3(1));
+    dim3 grid, block;
+    if (enqueueStripes(d, dX, dY, S.stream, &grid, &block)) { ERR("hipSpMVStripesCSR: launch failed"); return EXIT_FAILURE; }
+    L.shape(grid, block);                            // the persistent grid that ran: min(bins, CUs) workgroups of 256 threads
     return L.finish("hipSpMVStripesCSR");
 }
 
@@ -652,25 +686,21 @@ int hipSpMVTilesCSR(spmat* dMat, double* dX, CONFIG cfg, double* dY) {
     DevMat* d = descOf(dMat, "hipSpMVTilesCSR");
     if (!d) return EXIT_FAILURE;
     if (d->kind != Kind::CSR) { ERR("hipSpMVTilesCSR: handle is not CSR"); return EXIT_FAILURE; }
-    if (d->M == 0) return EXIT_SUCCESS;
-    if (d->NZ == 0) {                               // nothing to slice: y = 0
-        HIP_TRY(hipMemsetAsync(dY, 0, d->M * sizeof(double), S.stream));
-        if (S.sync) HIP_TRY(hipStreamSynchronize(S.stream));
-        return EXIT_SUCCESS;
-    }
+    if (d->M == 0 || d->NZ == 0) return nothingToLaunch(d, dY);         // nothing to slice: y = 0
     if (!d->tiles && buildTiles(d)) return EXIT_FAILURE;
     uint32_t bins = 0, rowsPerBin = 0;
     tilesShape(d, &bins, &rowsPerBin);
-    Launch L(dim3(bins), dim3(1024));                // phase 2's shape (phase 1: one workgroup per slice piece)
+    Launch L(grid2d((uint64_t)((bins + 7) / 8) * 8, 1024), dim3(1024));  // phase 2's shape (phase 1: one workgroup per slice piece)
     if (enqueueTiles(d, dX, dY, S.stream)) { ERR("hipSpMVTilesCSR: launch failed"); return EXIT_FAILURE; }
     return L.finish("hipSpMVTilesCSR");
 }
 
-// ---- hipSpMVAutoCSR: the fastest CSR launcher for THIS matrix, found by timing ----------------------------------
+// ---- the fastest reduction-order CSR launcher for THIS matrix, found by timing ----------------------------------
 // Which kernel wins depends on where x lives relative to the caches (DESIGN.md sections 4, 7, 8): the LDS-stream
 // kernel when the columns of neighbouring rows meet in L1/L2 (narrow bands, small matrices), the stripes kernel
 // while x fits the Infinity Cache, the two-phase kernel beyond.  A caller of the reference picks a kernel by name
-// (CUDA_CSR_ROWS_WARP ...); this entry point picks by measurement, once per handle, on the caller's own x: every
+// (CUDA_CSR_ROWS_WARP ...); hipSpMVAutoCSR -- and hipSpMVWarpPerRowCSR in its default variant 2, i.e. the reference's
+// name for "coalesced spans, on-chip reduction" -- pick by measurement, once per handle, on the caller's own x: every
 // eligible candidate computes y (one warm-up launch that also builds its format, AUTO_REPS timed ones), the fastest
 // stays, the formats of the others are released, and the chosen launcher runs once more so that y is its own.  The
 // first call is a normal -- slow -- SpMV and synchronises the stream even in enqueue-only mode.
@@ -679,7 +709,7 @@ constexpr int      AUTO_N = 3, AUTO_REPS = 3;
 constexpr uint64_t AUTO_MIN_NNZ = 1ull << 18;        // below this a launch is mostly latency: no private format pays
 constexpr uint64_t AUTO_STRIPES_X_BYTES = 256ull << 20;   // the stripes kernel re-reads x once per XCD and round of bins
 struct AutoCand { const char* name; SPMV_HIP* fn; };
-const AutoCand AUTO_CAND[AUTO_N] = {{"hipSpMVWarpPerRowCSR", &hipSpMVWarpPerRowCSR}, {"hipSpMVTilesCSR", &hipSpMVTilesCSR},
+const AutoCand AUTO_CAND[AUTO_N] = {{"hipSpMVWarpPerRowCSR", &warpStreamCSR}, {"hipSpMVTilesCSR", &hipSpMVTilesCSR},
                                     {"hipSpMVStripesCSR", &hipSpMVStripesCSR}};
 
 int autoSelect(spmat* dMat, DevMat* d, double* dX, CONFIG cfg, double* dY) {
@@ -690,20 +720,36 @@ int autoSelect(spmat* dMat, DevMat* d, double* dX, CONFIG cfg, double* dY) {
     hipEvent_t e0 = nullptr, e1 = nullptr;
     HIP_TRY(hipEventCreate(&e0));
     if (hipEventCreate(&e1) != hipSuccess) { (void)hipEventDestroy(e0); ERR("hipSpMVAutoCSR: event creation failed"); return EXIT_FAILURE; }
+    const bool wasSync = S.sync;
     int best = -1;
     float bestMs = 0;
-    for (int c = 0; c < AUTO_N; ++c) {
+    // Lower bound of a format kernel's time: its bytes per entry at the rate this HBM streams (MI355X_MICROARCH.md: 6.3 TB/s).
+    // A candidate whose BOUND is no better than what has already been measured cannot win: its format (12 B/nnz of memory,
+    // tens of B/nnz of temporaries, on c5's scale seconds of allocation) is not built.  Order: no format, 12 B/nnz, 28 B/nnz.
+    const double boundMs[AUTO_N] = {0.0, (double)d->NZ * 28.0 / 6.3e12 * 1e3, (double)d->NZ * 12.0 / 6.3e12 * 1e3};
+    const int order[AUTO_N] = {0, 2, 1};
+    for (int k = 0; k < AUTO_N; ++k) {
+        const int c = order[k];
         if (!eligible[c]) continue;
-        if (AUTO_CAND[c].fn(dMat, dX, cfg, dY)) continue;            // warm-up + format build; a candidate that fails is not a candidate
+        if (best >= 0 && boundMs[c] >= bestMs / AUTO_REPS) { d->autoMs[c] = 0; continue; }
+        // enqueue-only throughout (the library's own timing events belong to the device of spmvHipInit; this may run on another
+        // device's stream, spmvHipEnqueueAuto) and no host round trip inside e0..e1
+        S.sync = false;
+        const int rcWarm = AUTO_CAND[c].fn(dMat, dX, cfg, dY) || hipStreamSynchronize(S.stream) != hipSuccess;   // warm-up + format build
+        if (rcWarm) {                                                     // a candidate that fails is not a candidate ...
+            (void)hipGetLastError();                                      // ... and must not leave its error behind for the next one
+            continue;
+        }
         bool ok = hipEventRecord(e0, S.stream) == hipSuccess;
         for (int r = 0; ok && r < AUTO_REPS; ++r) ok = AUTO_CAND[c].fn(dMat, dX, cfg, dY) == EXIT_SUCCESS;
         float ms = 0;
         ok = ok && hipEventRecord(e1, S.stream) == hipSuccess && hipEventSynchronize(e1) == hipSuccess &&
              hipEventElapsedTime(&ms, e0, e1) == hipSuccess;
-        if (!ok) continue;
+        if (!ok) { (void)hipGetLastError(); continue; }
         d->autoMs[c] = ms / AUTO_REPS;
         if (best < 0 || ms < bestMs) { best = c; bestMs = ms; }
     }
+    S.sync = wasSync;
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
     if (best < 0) { ERR("hipSpMVAutoCSR: no candidate kernel ran"); return EXIT_FAILURE; }
@@ -715,20 +761,35 @@ int autoSelect(spmat* dMat, DevMat* d, double* dX, CONFIG cfg, double* dY) {
 }
 }  // namespace
 
-int hipSpMVAutoCSR(spmat* dMat, double* dX, CONFIG cfg, double* dY) {
-    DevMat* d = descOf(dMat, "hipSpMVAutoCSR");
+static int autoRun(spmat* dMat, double* dX, CONFIG cfg, double* dY, const char* who) {
+    DevMat* d = descOf(dMat, who);
     if (!d) return EXIT_FAILURE;
-    if (d->kind != Kind::CSR) { ERR("hipSpMVAutoCSR: handle is not CSR"); return EXIT_FAILURE; }
-    if (d->M == 0) return EXIT_SUCCESS;
+    if (d->kind != Kind::CSR) { ERR("%s: handle is not CSR", who); return EXIT_FAILURE; }
+    if (d->M == 0) return nothingToLaunch(d, nullptr);
     if (d->autoPick < 0 && autoSelect(dMat, d, dX, cfg, dY)) return EXIT_FAILURE;
     return AUTO_CAND[d->autoPick].fn(dMat, dX, cfg, dY);               // (also after the selection: y then is the chosen kernel's own)
 }
+
+int hipSpMVAutoCSR(spmat* dMat, double* dX, CONFIG cfg, double* dY) { return autoRun(dMat, dX, cfg, dY, "hipSpMVAutoCSR"); }
 
 const char* spmvHipAutoChoice(spmat* dMat, double* msPerCandidate) {
     DevMat* d = descOf(dMat, "spmvHipAutoChoice");
     if (!d || d->autoPick < 0) return nullptr;
     if (msPerCandidate) for (int c = 0; c < AUTO_N; ++c) msPerCandidate[c] = d->autoMs[c];
     return AUTO_CAND[d->autoPick].name;
+}
+
+// enqueue-only form of the selection's launcher on an explicit stream (shard.hip: one stream per device); the first call
+// for a handle measures the candidates on that stream and synchronises it
+int spmvHipEnqueueAuto(spmat* dMat, double* dX, double* dY, void* stream) {
+    hipStream_t keepStream = S.stream;
+    const bool keepSync = S.sync;
+    S.stream = static_cast<hipStream_t>(stream);
+    S.sync = false;
+    const int rc = autoRun(dMat, dX, CONFIG{}, dY, "spmvHipEnqueueAuto");
+    S.stream = keepStream;
+    S.sync = keepSync;
+    return rc;
 }
 
 static DevMat* tilesReady(spmat* dMat, const char* who) {
@@ -831,7 +892,7 @@ int hipSpMVRowsELL(spmat* dMat, double* dX, CONFIG cfg, double* dY) {
     DevMat* d = descOf(dMat, "hipSpMVRowsELL");
     if (!d) return EXIT_FAILURE;
     if (d->kind != Kind::ELL_COLMAJOR) { ERR("hipSpMVRowsELL: expects the transposed (column-major) ELL upload: ellTranspose() + spMatCpyELL()"); return EXIT_FAILURE; }
-    if (d->M == 0) return EXIT_SUCCESS;
+    if (d->M == 0) return nothingToLaunch(d, nullptr);
     const unsigned bt = blockThreads(cfg, BLOCKS_1D, 1024);
     const dim3 grid = grid2d((d->M + bt - 1) / bt, bt), block(bt);
     Launch L(grid, block);
@@ -845,7 +906,7 @@ int hipSpMVRowsELLNNTransposed(spmat* dMat, double* dX, CONFIG cfg, double* dY) 
     DevMat* d = descOf(dMat, "hipSpMVRowsELLNNTransposed");
     if (!d) return EXIT_FAILURE;
     if (d->kind != Kind::ELL_ROWMAJOR) { ERR("hipSpMVRowsELLNNTransposed: expects the row-major ELL upload (no ellTranspose)"); return EXIT_FAILURE; }
-    if (d->M == 0) return EXIT_SUCCESS;
+    if (d->M == 0) return nothingToLaunch(d, nullptr);
     const unsigned bt = blockThreads(cfg, BLOCKS_1D, 1024);
     const dim3 grid = grid2d((d->M + bt - 1) / bt, bt), block(bt);
     Launch L(grid, block);
@@ -859,7 +920,7 @@ int hipSpMVWarpsPerRowELLNTrasposed(spmat* dMat, double* dX, CONFIG cfg, double*
     DevMat* d = descOf(dMat, "hipSpMVWarpsPerRowELLNTrasposed");
     if (!d) return EXIT_FAILURE;
     if (d->kind != Kind::ELL_ROWMAJOR) { ERR("hipSpMVWarpsPerRowELLNTrasposed: expects the row-major ELL upload (no ellTranspose)"); return EXIT_FAILURE; }
-    if (d->M == 0) return EXIT_SUCCESS;
+    if (d->M == 0) return nothingToLaunch(d, nullptr);
     // lanes per row: the smallest power of two covering the slots, 4..64
     int G = 4;
     while (G < WAVE && (uint64_t)G < d->K) G <<= 1;

@@ -18,14 +18,8 @@
 namespace spmvhip {
 
 constexpr int      WAVE            = 64;
-#ifndef SPMV_WG_THREADS
-#define SPMV_WG_THREADS 256
-#endif
-#ifndef SPMV_STREAM_NNZ
-#define SPMV_STREAM_NNZ 2048
-#endif
-constexpr int      WG_THREADS      = SPMV_WG_THREADS;   // 4 wavefronts
-constexpr int      STREAM_NNZ      = SPMV_STREAM_NNZ;   // nnz staged in LDS per workgroup (16 KiB of fp64)
+constexpr int      WG_THREADS      = 256;               // 4 wavefronts
+constexpr int      STREAM_NNZ      = 2048;              // nnz staged in LDS per workgroup (16 KiB of fp64)
 // 32-bit row pointers are used only below this nnz count, so that `j + stride`
 // in the kernels can never wrap around 2^32
 constexpr uint64_t IRP32_LIMIT     = (1ull << 32) - 65536;
@@ -66,11 +60,11 @@ void freeSell(SellFormat* f);
 int  enqueueSell(DevMat* d, const double* x, double* y, hipStream_t stream);
 size_t sellBytes(const DevMat* d);
 
-int  buildStripes(DevMat* d);                                   // stripes.hip
+int  buildStripes(DevMat* d, const spmvStripesOpts* opts = nullptr);   // stripes.hip; explicit options replace an existing format
 void freeStripes(StripeFormat* f);
-int  enqueueStripes(DevMat* d, const double* x, double* y, hipStream_t stream);
+int  enqueueStripes(DevMat* d, const double* x, double* y, hipStream_t stream, dim3* grid = nullptr, dim3* block = nullptr);
 size_t stripesBytes(const DevMat* d);
-void stripesShape(const DevMat* d, uint32_t* bins, uint32_t* rowsPerBin, int* wide, double* buildMs);
+void stripesInfo(const DevMat* d, spmvStripesInfo* out);
 
 int  buildTiles(DevMat* d, const spmvTilesOpts* opts = nullptr); // tiles.hip; explicit options replace an existing format
 void tilesInfo(const DevMat* d, spmvTilesInfo* out);

@@ -42,7 +42,7 @@
 namespace spmvhip {
 
 constexpr uint32_t SELL_C       = 64;
-constexpr uint32_t SELL_SIGMA_DEFAULT = 1u << 14;   // rows per sorting window (SPMV_SELL_SIGMA overrides, for experiments)
+constexpr uint32_t SELL_SIGMA   = 1u << 14;         // rows per sorting window (a multiple of SELL_C)
 constexpr uint32_t SELL_MAX_ROW = 256;              // longer rows take the workgroup-per-row path (a long row would pin a lane, and pad its slice)
 
 struct SellFormat {
@@ -61,7 +61,7 @@ namespace {
 __device__ __forceinline__ uint64_t lin_block() { return (uint64_t)blockIdx.y * gridDim.x + blockIdx.x; }
 
 template <typename I>
-__global__ __launch_bounds__(256) void sell_keys_kernel(uint64_t M, uint64_t padded, uint32_t SELL_SIGMA, const I* __restrict__ IRP,
+__global__ __launch_bounds__(256) void sell_keys_kernel(uint64_t M, uint64_t padded, uint32_t sigma, const I* __restrict__ IRP,
                                                         uint64_t* __restrict__ keys, uint32_t* __restrict__ rows) {
     const uint64_t r = lin_block() * 256 + threadIdx.x;
     if (r >= padded) return;
@@ -71,7 +71,7 @@ __global__ __launch_bounds__(256) void sell_keys_kernel(uint64_t M, uint64_t pad
         if (len > SELL_MAX_ROW) len = 0;            // long rows occupy no slots (they sort to the window's end)
     }
     // ascending sort of (window, ~len): descending length inside each window; pad rows go last overall
-    keys[r] = r < M ? ((r / SELL_SIGMA) << 32 | (0xFFFFFFFFull - len)) : ~0ull;
+    keys[r] = r < M ? ((r / sigma) << 32 | (0xFFFFFFFFull - len)) : ~0ull;
     rows[r] = r < M ? (uint32_t)r : 0xFFFFFFFFu;
 }
 
@@ -211,8 +211,7 @@ int buildSellT(DevMat* d, SellFormat* f) {
     SELL_TRY(hipMalloc(&f->slen, std::max<size_t>(padded, 1) * 4));
     SELL_TRY(hipMalloc(&f->sliceOff, ((size_t)f->nSlices + 1) * 8));
     const dim3 gRows = grid2d((padded + 255) / 256, 256);
-    uint32_t sigma = SELL_SIGMA_DEFAULT;
-    if (const char* e = getenv("SPMV_SELL_SIGMA")) { const long v = atol(e); if (v >= 64) sigma = (uint32_t)(v / 64 * 64); }   // whole slices: a window that ends inside a slice would break "first row of a slice is its longest"
+    const uint32_t sigma = SELL_SIGMA;              // whole slices: a window that ends inside a slice would break "first row of a slice is its longest"
     hipLaunchKernelGGL((sell_keys_kernel<I>), gRows, dim3(256), 0, nullptr, M, padded, sigma, IRP, keys.as<uint64_t>(), rows.as<uint32_t>());
     size_t tmpBytes = 0;
     SELL_TRY(rocprim::radix_sort_pairs(nullptr, tmpBytes, keys.as<uint64_t>(), keysOut.as<uint64_t>(), rows.as<uint32_t>(), f->perm,

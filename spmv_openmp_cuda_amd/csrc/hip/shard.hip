@@ -1,21 +1,29 @@
 // shard.hip -- single-process, multi-device SpMV for the plain-C drivers:
-// nnz-balanced contiguous row blocks, x replicated, one RCCL all-gather of y
-// over xGMI.  New functionality: the reference is single-GPU
+// nnz-balanced contiguous row blocks, x replicated, RCCL all-gather of y over
+// xGMI.  New functionality: the reference is single-GPU
 // (no MPI/NCCL/cudaSetDevice anywhere in it).
 //
+// Every device's rows are cut into G consecutive row GROUPS (nDev x G blocks in
+// all, still balanced by nnz).  A step runs, per device,
+//     kernel(g) on the compute stream -> all-gather(g) on the gather stream
+// for g = 0..G-1, so the gather of group g travels while group g+1 is computed
+// (xGMI is point-to-point: at 2..8 devices the gather costs about as much as the
+// kernel).  mode 1 runs the kernel hipSpMVWarpPerRowCSR would (the fastest
+// reduction-order kernel for each block, measured at the first step); mode 0 the
+// serial-order kernel of hipSpMVRowsCSR (bit-identical to the 1-GPU result).
+//
 // bench.py does NOT use this file: it runs one process per GPU and gathers with
-// torch.distributed (RCCL).  RCCL is loaded lazily with dlopen so that
-// libspmvhip.so carries no link-time dependency on it (a Python process that
-// imported torch already holds torch's own librccl).
+// torch.distributed (RCCL) or peer windows.  RCCL is loaded lazily with dlopen so
+// that libspmvhip.so carries no link-time dependency on it (a Python process
+// that imported torch already holds torch's own librccl).
 #include <hip/hip_runtime.h>
 #include <dlfcn.h>
+#include <algorithm>
 #include <cstring>
 #include <vector>
 
 #include "spmvHip.h"
 #include "device_mat.hpp"
-
-extern "C" int spmvHipEnqueueCSR(spmat* dMat, int warpPerRow, double* dX, double* dY, void* stream);
 
 namespace {
 
@@ -46,19 +54,71 @@ struct Rccl {
     }
 } rccl;
 
+// the calling thread's current device is put back on every way out
+struct DeviceGuard {
+    int keep = -1;
+    DeviceGuard() { if (hipGetDevice(&keep) != hipSuccess) keep = -1; }
+    ~DeviceGuard() { if (keep >= 0) (void)hipSetDevice(keep); }
+};
+
 struct Shard {
-    int nDev = 0;
-    ulong M = 0, N = 0, maxRows = 0;
-    std::vector<ulong> bounds;
-    std::vector<spmat> mats;
-    std::vector<double*> dX, dYpad;
-    std::vector<hipStream_t> streams;
-    std::vector<hipEvent_t> ev0, ev1, ev2;
+    int nDev = 0, G = 1;
+    ulong M = 0, N = 0;
+    std::vector<ulong> bounds;               // [nDev*G + 1]; block k = device k / G, group k % G
+    std::vector<ulong> maxRows;              // [G] largest block of the group over the devices
+    std::vector<spmat> mats;                 // [nDev*G]
+    std::vector<double*> dX;                 // [nDev]
+    std::vector<double*> dYpad;              // [nDev*G]: nDev * maxRows[g] doubles; device d's rows of group g sit in slot d
+    std::vector<hipStream_t> compute, gather;
+    std::vector<hipEvent_t> evStart, evEnd;  // [nDev] first kernel starts / last gather done
+    std::vector<hipEvent_t> evK0, evK1;      // [nDev*G] around each group's kernel
     std::vector<ncclComm_t> comms;
     bool useRccl = false;
+    bool selected = false;                   // mode 1: the per-block kernel selection has run
+    ulong lo(int d, int g) const { return bounds[(size_t)d * G + g]; }
+    ulong hi(int d, int g) const { return bounds[(size_t)d * G + g + 1]; }
 };
 
 #define NCCL_TRY(expr) do { ncclResult_t r_ = (expr); if (r_ != 0) { fprintf(stderr, "libspmvhip: %s: %s\n", #expr, rccl.GetErrorString(r_)); return EXIT_FAILURE; } } while (0)
+
+int shardStep(Shard* sh, const double* hX, int mode, bool timed) {
+    const int n = sh->nDev, G = sh->G;
+    for (int d = 0; d < n; ++d) {
+        HIP_TRY(hipSetDevice(d));
+        HIP_TRY(hipMemcpyAsync(sh->dX[d], hX, sh->N * sizeof(double), hipMemcpyHostToDevice, sh->compute[d]));
+        for (int g = 0; g < G; ++g)
+            HIP_TRY(hipMemsetAsync(sh->dYpad[(size_t)d * G + g], 0xFF, (size_t)n * std::max<ulong>(sh->maxRows[g], 1) * sizeof(double), sh->compute[d]));   // NaN poison
+        if (timed) HIP_TRY(hipEventRecord(sh->evStart[d], sh->compute[d]));
+    }
+    for (int g = 0; g < G; ++g) {
+        const ulong pad = std::max<ulong>(sh->maxRows[g], 1);
+        for (int d = 0; d < n; ++d) {
+            HIP_TRY(hipSetDevice(d));
+            const size_t k = (size_t)d * G + g;
+            double* slot = sh->dYpad[k] + (size_t)d * pad;
+            if (timed) HIP_TRY(hipEventRecord(sh->evK0[k], sh->compute[d]));
+            const int rc = mode ? spmvHipEnqueueAuto(&sh->mats[k], sh->dX[d], slot, sh->compute[d])
+                                : spmvHipEnqueueCSR(&sh->mats[k], 0, sh->dX[d], slot, sh->compute[d]);
+            if (rc) return EXIT_FAILURE;
+            HIP_TRY(hipEventRecord(sh->evK1[k], sh->compute[d]));
+            HIP_TRY(hipStreamWaitEvent(sh->gather[d], sh->evK1[k], 0));      // (the first group's wait also orders the poison before the gather)
+        }
+        if (sh->useRccl) {
+            NCCL_TRY(rccl.GroupStart());
+            for (int d = 0; d < n; ++d) {
+                const size_t k = (size_t)d * G + g;
+                NCCL_TRY(rccl.AllGather(sh->dYpad[k] + (size_t)d * pad, sh->dYpad[k], pad, kNcclFloat64, sh->comms[d], sh->gather[d]));
+            }
+            NCCL_TRY(rccl.GroupEnd());
+        }
+    }
+    for (int d = 0; d < n; ++d) {
+        HIP_TRY(hipSetDevice(d));
+        HIP_TRY(hipEventRecord(sh->evEnd[d], sh->gather[d]));
+        HIP_TRY(hipEventSynchronize(sh->evEnd[d]));
+    }
+    return EXIT_SUCCESS;
+}
 
 }  // namespace
 
@@ -67,52 +127,65 @@ extern "C" {
 int spmvHipShardFree(void* handle) {
     Shard* sh = static_cast<Shard*>(handle);
     if (!sh) return EXIT_SUCCESS;
-    int keep = 0;
-    (void)hipGetDevice(&keep);
+    DeviceGuard guard;
     for (int d = 0; d < sh->nDev; ++d) {
         (void)hipSetDevice(d);
-        if (d < (int)sh->mats.size()) hipFreeSpmat(&sh->mats[d]);
+        for (int g = 0; g < sh->G; ++g) {
+            const size_t k = (size_t)d * sh->G + g;
+            if (k < sh->mats.size()) hipFreeSpmat(&sh->mats[k]);
+            if (k < sh->dYpad.size()) (void)hipFree(sh->dYpad[k]);
+            if (k < sh->evK0.size() && sh->evK0[k]) (void)hipEventDestroy(sh->evK0[k]);
+            if (k < sh->evK1.size() && sh->evK1[k]) (void)hipEventDestroy(sh->evK1[k]);
+        }
         if (d < (int)sh->dX.size()) (void)hipFree(sh->dX[d]);
-        if (d < (int)sh->dYpad.size()) (void)hipFree(sh->dYpad[d]);
-        if (d < (int)sh->ev0.size()) { (void)hipEventDestroy(sh->ev0[d]); (void)hipEventDestroy(sh->ev1[d]); (void)hipEventDestroy(sh->ev2[d]); }
-        if (d < (int)sh->streams.size()) (void)hipStreamDestroy(sh->streams[d]);
+        if (d < (int)sh->evStart.size() && sh->evStart[d]) (void)hipEventDestroy(sh->evStart[d]);
+        if (d < (int)sh->evEnd.size() && sh->evEnd[d]) (void)hipEventDestroy(sh->evEnd[d]);
+        if (d < (int)sh->compute.size() && sh->compute[d]) (void)hipStreamDestroy(sh->compute[d]);
+        if (d < (int)sh->gather.size() && sh->gather[d]) (void)hipStreamDestroy(sh->gather[d]);
         if (d < (int)sh->comms.size() && sh->comms[d]) rccl.CommDestroy(sh->comms[d]);
     }
-    (void)hipSetDevice(keep);
     delete sh;
     return EXIT_SUCCESS;
 }
 
-int spmvHipShardCSR(spmat* host, int nDev, void** shardHandle) {
-    if (!host || !shardHandle || nDev <= 0) return EXIT_FAILURE;
-    int visible = spmvHipDeviceCount();
+int spmvHipShardCSRGroups(spmat* host, int nDev, int groups, void** shardHandle) {
+    if (!host || !shardHandle || nDev <= 0 || groups < 0 || groups > 64) return EXIT_FAILURE;
+    const int visible = spmvHipDeviceCount();
     if (nDev > visible) { fprintf(stderr, "libspmvhip: spmvHipShardCSR: %d devices requested, %d visible\n", nDev, visible); return EXIT_FAILURE; }
-    int keep = 0;
-    HIP_TRY(hipGetDevice(&keep));
+    DeviceGuard guard;
     Shard* sh = new Shard;
-    sh->nDev = nDev; sh->M = host->M; sh->N = host->N;
-    sh->bounds.resize(nDev + 1);
-    if (spmvHipPartitionRows(host->IRP, host->M, nDev, sh->bounds.data())) { delete sh; return EXIT_FAILURE; }
-    for (int d = 0; d < nDev; ++d) sh->maxRows = std::max(sh->maxRows, sh->bounds[d + 1] - sh->bounds[d]);
+    const int G = groups ? groups : (nDev > 1 ? 2 : 1);
+    sh->nDev = nDev; sh->G = G; sh->M = host->M; sh->N = host->N;
+    const size_t nBlk = (size_t)nDev * G;
+    sh->bounds.resize(nBlk + 1);
+    if (spmvHipPartitionRows(host->IRP, host->M, (int)nBlk, sh->bounds.data())) { delete sh; return EXIT_FAILURE; }
+    sh->maxRows.assign(G, 0);
+    for (int d = 0; d < nDev; ++d)
+        for (int g = 0; g < G; ++g) sh->maxRows[g] = std::max(sh->maxRows[g], sh->hi(d, g) - sh->lo(d, g));
     const char* force = getenv("SPMV_SHARD_FORCE_RCCL");
     sh->useRccl = nDev > 1 || (force && *force == '1');
-    sh->mats.resize(nDev); sh->dX.assign(nDev, nullptr); sh->dYpad.assign(nDev, nullptr);
-    sh->streams.assign(nDev, nullptr); sh->ev0.assign(nDev, nullptr); sh->ev1.assign(nDev, nullptr); sh->ev2.assign(nDev, nullptr);
+    sh->mats.resize(nBlk); sh->dX.assign(nDev, nullptr); sh->dYpad.assign(nBlk, nullptr);
+    sh->compute.assign(nDev, nullptr); sh->gather.assign(nDev, nullptr);
+    sh->evStart.assign(nDev, nullptr); sh->evEnd.assign(nDev, nullptr); sh->evK0.assign(nBlk, nullptr); sh->evK1.assign(nBlk, nullptr);
     for (auto& m : sh->mats) memset(&m, 0, sizeof m);
     int rc = EXIT_SUCCESS;
     for (int d = 0; d < nDev && !rc; ++d) {
         if (hipSetDevice(d) != hipSuccess) { rc = EXIT_FAILURE; break; }
-        spmat* blk = spmvHipRowBlockCSR(host, sh->bounds[d], sh->bounds[d + 1]);
-        if (!blk) { rc = EXIT_FAILURE; break; }
-        rc = spMatCpyCSR(blk, &sh->mats[d]);
-        free(blk->IRP); free(blk->JA); free(blk->AS); free(blk->RL); free(blk);
-        if (rc) break;
         if (hipMalloc(&sh->dX[d], std::max<size_t>(sh->N, 1) * sizeof(double)) != hipSuccess ||
-            hipMalloc(&sh->dYpad[d], std::max<size_t>((size_t)nDev * sh->maxRows, 1) * sizeof(double)) != hipSuccess ||
-            hipStreamCreateWithFlags(&sh->streams[d], hipStreamNonBlocking) != hipSuccess ||
-            hipEventCreate(&sh->ev0[d]) != hipSuccess || hipEventCreate(&sh->ev1[d]) != hipSuccess ||
-            hipEventCreate(&sh->ev2[d]) != hipSuccess)
-            rc = EXIT_FAILURE;
+            hipStreamCreateWithFlags(&sh->compute[d], hipStreamNonBlocking) != hipSuccess ||
+            hipStreamCreateWithFlags(&sh->gather[d], hipStreamNonBlocking) != hipSuccess ||
+            hipEventCreate(&sh->evStart[d]) != hipSuccess || hipEventCreate(&sh->evEnd[d]) != hipSuccess) { rc = EXIT_FAILURE; break; }
+        for (int g = 0; g < G && !rc; ++g) {
+            const size_t k = (size_t)d * G + g;
+            spmat* blk = spmvHipRowBlockCSR(host, sh->lo(d, g), sh->hi(d, g));
+            if (!blk) { rc = EXIT_FAILURE; break; }
+            rc = spMatCpyCSR(blk, &sh->mats[k]);
+            free(blk->IRP); free(blk->JA); free(blk->AS); free(blk->RL); free(blk);
+            if (rc) break;
+            if (hipMalloc(&sh->dYpad[k], (size_t)nDev * std::max<ulong>(sh->maxRows[g], 1) * sizeof(double)) != hipSuccess ||
+                hipEventCreate(&sh->evK0[k]) != hipSuccess || hipEventCreate(&sh->evK1[k]) != hipSuccess)
+                rc = EXIT_FAILURE;
+        }
     }
     if (!rc && sh->useRccl) {
         if (!rccl.load()) rc = EXIT_FAILURE;
@@ -124,54 +197,51 @@ int spmvHipShardCSR(spmat* host, int nDev, void** shardHandle) {
             if (r != 0) { fprintf(stderr, "libspmvhip: ncclCommInitAll: %s\n", rccl.GetErrorString(r)); rc = EXIT_FAILURE; }
         }
     }
-    (void)hipSetDevice(keep);
     if (rc) { spmvHipShardFree(sh); return EXIT_FAILURE; }
     *shardHandle = sh;
     return EXIT_SUCCESS;
 }
 
-// mode: 0 = thread-per-row semantics (hipSpMVRowsCSR), 1 = wavefront semantics (hipSpMVWarpPerRowCSR)
+int spmvHipShardCSR(spmat* host, int nDev, void** shardHandle) { return spmvHipShardCSRGroups(host, nDev, 0, shardHandle); }
+
+// mode: 0 = hipSpMVRowsCSR (serial order, bit-identical to the 1-GPU y), != 0 = hipSpMVWarpPerRowCSR (the fastest
+// reduction-order kernel per block; chosen by an untimed pass at the first call)
 int spmvHipSpMVSharded(void* handle, const double* hX, int mode, double* hY, double* kernelSec, double* gatherSec) {
     Shard* sh = static_cast<Shard*>(handle);
     if (!sh || !hX || !hY) return EXIT_FAILURE;
-    int keep = 0;
-    HIP_TRY(hipGetDevice(&keep));
-    const int n = sh->nDev;
+    DeviceGuard guard;
+    const int n = sh->nDev, G = sh->G;
+    if (mode && !sh->selected) {
+        if (shardStep(sh, hX, mode, false)) return EXIT_FAILURE;
+        sh->selected = true;
+    }
+    if (shardStep(sh, hX, mode, true)) return EXIT_FAILURE;
+    double kmax = 0, tmax = 0;
     for (int d = 0; d < n; ++d) {
         HIP_TRY(hipSetDevice(d));
-        HIP_TRY(hipMemcpyAsync(sh->dX[d], hX, sh->N * sizeof(double), hipMemcpyHostToDevice, sh->streams[d]));
-        HIP_TRY(hipMemsetAsync(sh->dYpad[d], 0xFF, (size_t)n * sh->maxRows * sizeof(double), sh->streams[d]));   // NaN poison
-        HIP_TRY(hipEventRecord(sh->ev0[d], sh->streams[d]));
-        if (spmvHipEnqueueCSR(&sh->mats[d], mode != 0, sh->dX[d], sh->dYpad[d] + (size_t)d * sh->maxRows, sh->streams[d])) return EXIT_FAILURE;
-        HIP_TRY(hipEventRecord(sh->ev1[d], sh->streams[d]));
-    }
-    if (sh->useRccl) {
-        NCCL_TRY(rccl.GroupStart());
-        for (int d = 0; d < n; ++d)
-            NCCL_TRY(rccl.AllGather(sh->dYpad[d] + (size_t)d * sh->maxRows, sh->dYpad[d], sh->maxRows, kNcclFloat64,
-                                    sh->comms[d], sh->streams[d]));
-        NCCL_TRY(rccl.GroupEnd());
-    }
-    double kmax = 0, gmax = 0;
-    for (int d = 0; d < n; ++d) {
-        HIP_TRY(hipSetDevice(d));
-        HIP_TRY(hipEventRecord(sh->ev2[d], sh->streams[d]));
-        HIP_TRY(hipEventSynchronize(sh->ev2[d]));
-        float k = 0, g = 0;
-        HIP_TRY(hipEventElapsedTime(&k, sh->ev0[d], sh->ev1[d]));
-        HIP_TRY(hipEventElapsedTime(&g, sh->ev1[d], sh->ev2[d]));
-        kmax = std::max<double>(kmax, k * 1e-3);
-        gmax = std::max<double>(gmax, g * 1e-3);
+        float total = 0;
+        double ksum = 0;
+        HIP_TRY(hipEventElapsedTime(&total, sh->evStart[d], sh->evEnd[d]));
+        for (int g = 0; g < G; ++g) {
+            float k = 0;
+            HIP_TRY(hipEventElapsedTime(&k, sh->evK0[(size_t)d * G + g], sh->evK1[(size_t)d * G + g]));
+            ksum += k * 1e-3;
+        }
+        kmax = std::max(kmax, ksum);
+        tmax = std::max<double>(tmax, total * 1e-3);
     }
     // every device now holds all blocks; read them back from device 0, compacted
     HIP_TRY(hipSetDevice(0));
-    for (int p = 0; p < n; ++p) {
-        const ulong rows = sh->bounds[p + 1] - sh->bounds[p];
-        if (rows) HIP_TRY(hipMemcpy(hY + sh->bounds[p], sh->dYpad[0] + (size_t)p * sh->maxRows, rows * sizeof(double), hipMemcpyDeviceToHost));
+    for (int g = 0; g < G; ++g) {
+        const ulong pad = std::max<ulong>(sh->maxRows[g], 1);
+        for (int p = 0; p < n; ++p) {
+            if (p != 0 && !sh->useRccl) continue;
+            const ulong rows = sh->hi(p, g) - sh->lo(p, g);
+            if (rows) HIP_TRY(hipMemcpy(hY + sh->lo(p, g), sh->dYpad[g] + (size_t)p * pad, rows * sizeof(double), hipMemcpyDeviceToHost));
+        }
     }
-    (void)hipSetDevice(keep);
-    if (kernelSec) *kernelSec = kmax;
-    if (gatherSec) *gatherSec = gmax;
+    if (kernelSec) *kernelSec = kmax;                       // kernels of all row groups, slowest device
+    if (gatherSec) *gatherSec = std::max(0.0, tmax - kmax); // what the exchange adds to the step after overlap
     return EXIT_SUCCESS;
 }
 

@@ -36,6 +36,13 @@
 // the column order.  Sums are added in arrival order: equal to the serial oracle to rounding, not bitwise.
 //
 // The format is built ON THE DEVICE from the device CSR (rocPRIM radix sort of (bin, column) keys; c3: ~60 ms).
+//
+// DETERMINISTIC form (spmvStripesOpts.deterministic): every row of a bin is OWNED by one of the workgroup's
+// wavefronts (local row mod 4); each wavefront has its own column-ordered sub-stream of the bin and walks it in
+// program order, so a row's products are added by one wavefront in ascending column order -- the order of the
+// serial oracle -- whatever the scheduler does.  No ticket counter, no staggered start.  The four wavefronts
+// still sweep x together (each sub-stream spans all columns), but a gather instruction now covers 64 neighbours
+// of a QUARTER of the bin's entries, so it touches more lines (c3: ~60 instead of ~47 per 64 entries).
 #include <hip/hip_runtime.h>
 #include <cstring>
 #include <rocprim/device/device_radix_sort.hpp>
@@ -48,38 +55,31 @@
 namespace spmvhip {
 
 constexpr uint32_t SB_R_MAX   = 20000;              // rows per bin: <= 156.25 KiB of y in LDS
-#ifndef SPMV_SB_THREADS
-#define SPMV_SB_THREADS 256
-#endif
-constexpr int      SB_THREADS = SPMV_SB_THREADS;
+constexpr int      SB_THREADS = 256;                // 4 wavefronts: fewer, deeper wavefronts keep the gathers in flight close together in x
 constexpr uint32_t SB_WAVES   = SB_THREADS / 64;
 constexpr uint32_t SB_STEP    = 128;                // entries per wavefront step (two per lane)
 constexpr uint32_t SB_ROWBITS = 15;
 constexpr uint32_t SB_NONE    = (1u << SB_ROWBITS) - 1;     // local row of a padding entry (SB_R_MAX < SB_NONE)
 constexpr uint32_t SB_DCOL_LIMIT = 1u << (32 - SB_ROWBITS);
-#ifndef SPMV_SB_DEPTH
-#define SPMV_SB_DEPTH 6
-#endif
-constexpr int      SB_DEPTH   = SPMV_SB_DEPTH;      // steps per register batch
-constexpr uint32_t SB_CUS     = 256;
-#ifndef SPMV_SB_SPREAD
-#define SPMV_SB_SPREAD 6
-#endif
-constexpr uint32_t SB_SPREAD  = SPMV_SB_SPREAD;     // 1/1024ths of a bin over which the sweeps of one XCD's workgroups start
+constexpr int      SB_DEPTH   = 6;                  // steps per register batch
+constexpr uint32_t SB_SPREAD  = 6;                  // 1/1024ths of a bin over which the sweeps of one XCD's workgroups start
 constexpr uint64_t SB_MIN_BIN_NNZ = 16384;          // do not cut a small matrix into bins shorter than this
 
 struct StripeFormat {
     uint32_t  B = 0, R = 0;                         // bins, rows of the highest bin
+    uint32_t  subs = 1;                             // column-ordered sub-streams per bin: 1, or SB_WAVES in the deterministic form
     uint64_t  nnz = 0, nSteps = 0;
-    bool      wide = false;
-    double*   val = nullptr;                        // [nSteps * 128] bin-major, column order inside a bin, bins padded to whole steps
+    bool      wide = false, det = false;
+    double*   val = nullptr;                        // [nSteps * 128] sub-stream-major, column order inside a sub-stream, each padded to whole steps
     uint32_t* cr = nullptr;                         // narrow: (column - stepBase) << 15 | local row;  wide: column
     uint16_t* lrowW = nullptr;                      // wide only: local row
     uint32_t* stepBase = nullptr;                   // narrow only: [nSteps] first column of the step
     uint32_t* binRow = nullptr;                     // [B+1] first row of each bin
-    uint32_t* binStep = nullptr;                    // [B+1] first step of each bin
+    uint32_t* subStep = nullptr;                    // [B*subs+1] first step of each sub-stream
+    uint32_t  grid = 1, spread = SB_SPREAD;         // persistent workgroups (one per CU of the device the format was built on), start spread
     size_t    bytes = 0;
     double    buildMs = 0;
+    spmvStripesOpts opts{0, 0, -1, -1, 0};          // what the format was built with (0 / -1 = automatic)
 };
 
 namespace {
@@ -91,10 +91,11 @@ typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 typedef uint16_t u16x2 __attribute__((ext_vector_type(2)));
 
 // ---- build kernels ---------------------------------------------------------------------------------------
-// key = bin << colBits | column, payload = CSR position; one wavefront per row
+// key = (bin * subs + owner) << colBits | column, payload = CSR position; one wavefront per row.  owner = the wavefront
+// that adds this row in the deterministic form (local row mod subs), 0 otherwise.
 template <typename I>
 __global__ __launch_bounds__(256) void sb_keys_kernel(uint64_t M, const I* __restrict__ IRP, const uint32_t* __restrict__ JA,
-                                                      const uint32_t* __restrict__ binRow, uint32_t B, unsigned colBits,
+                                                      const uint32_t* __restrict__ binRow, uint32_t B, uint32_t subs, unsigned colBits,
                                                       uint64_t* __restrict__ keys, uint32_t* __restrict__ idx,
                                                       uint32_t* __restrict__ rowOf) {
     const uint64_t r = lin_block() * 4 + threadIdx.x / 64;
@@ -104,34 +105,50 @@ __global__ __launch_bounds__(256) void sb_keys_kernel(uint64_t M, const I* __res
         const uint32_t mid = lo + (hi - lo) / 2;
         if (binRow[mid] <= r) lo = mid; else hi = mid;
     }
+    const uint64_t group = (uint64_t)lo * subs + ((uint32_t)r - binRow[lo]) % subs;
     const uint64_t b = IRP[r], e = IRP[r + 1];
     for (uint64_t j = b + threadIdx.x % 64; j < e; j += 64) {
-        keys[j] = (uint64_t)lo << colBits | JA[j];
+        keys[j] = group << colBits | JA[j];
         idx[j] = (uint32_t)j;
         rowOf[j] = (uint32_t)r;
     }
 }
 
-// sorted position p -> padded position q of its bin; values, encoded columns / rows, step bases
+// where each group (sub-stream) starts in the sorted order: the group id is non-decreasing along it, so the first entry of
+// a group also fills the start of every empty group before it
+__global__ __launch_bounds__(256) void sb_bounds_kernel(uint64_t nnz, unsigned colBits, const uint64_t* __restrict__ skeys,
+                                                        uint64_t nGroups, uint64_t* __restrict__ start) {
+    const uint64_t p = lin_block() * 256 + threadIdx.x;
+    if (p >= nnz) return;
+    const uint64_t g = skeys[p] >> colBits;
+    const uint64_t gPrev = p ? skeys[p - 1] >> colBits : ~0ull;
+    if (g != gPrev)
+        for (uint64_t u = gPrev + 1; u <= g; ++u) start[u] = p;          // gPrev + 1 wraps to 0 for p == 0
+    if (p == nnz - 1)
+        for (uint64_t u = g + 1; u <= nGroups; ++u) start[u] = nnz;
+}
+
+// sorted position p -> padded position q of its sub-stream; values, encoded columns / rows, step bases
 template <bool WIDE>
 __global__ __launch_bounds__(256) void sb_scatter_kernel(
-    uint64_t nnz, unsigned colBits, const uint64_t* __restrict__ skeys, const uint32_t* __restrict__ perm,
+    uint64_t nnz, unsigned colBits, uint32_t subs, const uint64_t* __restrict__ skeys, const uint32_t* __restrict__ perm,
     const uint32_t* __restrict__ rowOf, const double* __restrict__ AS, const uint32_t* __restrict__ binRow,
-    const uint64_t* __restrict__ binStart, const uint32_t* __restrict__ binStep,
+    const uint64_t* __restrict__ start, const uint32_t* __restrict__ subStep,
     double* __restrict__ val, uint32_t* __restrict__ cr, uint16_t* __restrict__ lrowW, uint32_t* __restrict__ stepBase,
     uint32_t* __restrict__ overflow) {
     const uint64_t p = lin_block() * 256 + threadIdx.x;
     if (p >= nnz) return;
     const uint64_t key = skeys[p];
-    const uint32_t bin = (uint32_t)(key >> colBits);
+    const uint64_t group = key >> colBits;
+    const uint32_t bin = (uint32_t)(group / subs);
     const uint32_t col = (uint32_t)(key & ((1ull << colBits) - 1));
-    const uint64_t pos = p - binStart[bin];
+    const uint64_t pos = p - start[group];
     // inside a step the 128 column-ordered entries are dealt to the lanes as (e, 64 + e): lane l reads the pair at
     // positions 2l, 2l + 1 with one 16-byte load, and each of the step's two gather instructions covers 64 NEIGHBOURING
     // entries (lanes share lines inside an instruction; the two instructions touch different lines -- with (2l, 2l + 1)
     // pairs the second gather hit lines still pending from the first and stalled the L1: TCP_PENDING_STALL_CYCLES)
     const uint64_t e = pos % SB_STEP;
-    const uint64_t q = (uint64_t)binStep[bin] * SB_STEP + (pos - e) + (e < SB_STEP / 2 ? 2 * e : 2 * (e - SB_STEP / 2) + 1);
+    const uint64_t q = (uint64_t)subStep[group] * SB_STEP + (pos - e) + (e < SB_STEP / 2 ? 2 * e : 2 * (e - SB_STEP / 2) + 1);
     const uint32_t j = perm[p];
     const uint32_t lrow = rowOf[j] - binRow[bin];
     val[q] = AS[j];
@@ -139,12 +156,11 @@ __global__ __launch_bounds__(256) void sb_scatter_kernel(
         cr[q] = col;
         lrowW[q] = (uint16_t)lrow;
     } else {
-        const uint64_t inStep = e;
-        const uint32_t base = (uint32_t)(skeys[p - inStep] & ((1ull << colBits) - 1));
+        const uint32_t base = (uint32_t)(skeys[p - e] & ((1ull << colBits) - 1));      // first entry of the step: same sub-stream
         const uint32_t d = col - base;
         if (d >= SB_DCOL_LIMIT) atomicOr(overflow, 1u);
         cr[q] = d << SB_ROWBITS | lrow;
-        if (inStep == 0) stepBase[q / SB_STEP] = base;
+        if (e == 0) stepBase[q / SB_STEP] = base;
     }
 }
 
@@ -158,25 +174,30 @@ __global__ __launch_bounds__(256) void sb_fill16_kernel(uint16_t* __restrict__ p
 }
 
 // ---- the SpMV kernel -------------------------------------------------------------------------------------
-// A batch = SB_DEPTH consecutive steps of the bin.  Batches are handed to the 16 wavefronts of the bin's workgroup
-// through a ticket counter in LDS, NOT by a fixed wavefront -> batch map: the scheduler favours the oldest
-// wavefront of a workgroup, and with a fixed map wavefront 0 finished its share after a quarter of the bin's time
-// while the youngest needed all of it -- sixteen sweeps of x at sixteen different places, and the L2 kept none of
-// them (c3: 52 % hits, 10 GB fetched for 2.6 GB; profiles/r02_stripes.md).  With tickets the workgroup has ONE
-// frontier: a faster wavefront simply takes more batches.
+// A batch = SB_DEPTH consecutive steps of a sub-stream.  In the default form the bin is ONE sub-stream and its batches are
+// handed to the wavefronts of the bin's workgroup through a ticket counter in LDS, NOT by a fixed wavefront -> batch map:
+// the scheduler favours the oldest wavefront of a workgroup, and with a fixed map wavefront 0 finished its share after a
+// quarter of the bin's time while the youngest needed all of it -- several sweeps of x at different places, and the L2 kept
+// none of them (c3: 52 % hits, 10 GB fetched for 2.6 GB; profiles/r02_stripes.md).  With tickets the workgroup has ONE
+// frontier: a faster wavefront simply takes more batches.  In the deterministic form every wavefront walks its OWN
+// sub-stream (the rows it owns) batch by batch in program order.
 // Three stages per batch -- stream loads (values, column/row words; non-temporal), x gathers, LDS adds -- are kept
 // apart by TWO batches of stream loads: vmcnt counts in issue order, so a gather may only be waited for while
 // younger stream loads are outstanding if those were issued AFTER it.  Issue order of iteration k:
 //     gather(k+1) [needs stream(k+1), issued two iterations ago], stream(k+3), add(k) [needs gather(k)]
 // Four stream batches and two gather batches rotate through registers (the loop body is written out four times
-// so that every batch is a named register set).  Steps past the bin's end are clamped to its last step (a valid,
+// so that every batch is a named register set).  Steps past the sub-stream's end are clamped to its last step (a valid,
 // cached address) and skipped when adding: no branch around a load, the compiler's vmcnt stays exact.
+// (Measured and settled in round 2, logs under profiles/r02_stripes_*: `nt` stream loads beat plain ones by 8 %; plain
+// gathers -- `nt` ones no longer allocate in L2, 2.3 ms; buffer / scalar-base address forms of the gather equal; the kernel
+// without its LDS adds is no faster, without its gathers it is the 12 B/nnz stream.)
 struct SbStream { dbl2 v[SB_DEPTH]; u32x2 c[SB_DEPTH]; u16x2 r[SB_DEPTH]; uint32_t base[SB_DEPTH]; uint32_t first; };
 struct SbGather { double x0[SB_DEPTH], x1[SB_DEPTH]; };
 
-// stream loads of the batch with ticket `t` (wavefront-uniform).  A bin has nb batches of SB_DEPTH steps; ticket t stands
-// for batch (t + off) mod nb -- the workgroup starts its column sweep `off` batches into the bin and wraps around (the
-// order in which a bin's entries are added is free) -- and tickets >= nb for nothing (first = s1: loads clamped, adds skipped).
+// stream loads of the batch with ticket `t` (wavefront-uniform).  A sub-stream has nb batches of SB_DEPTH steps; ticket t
+// stands for batch (t + off) mod nb -- the workgroup starts its column sweep `off` batches into the bin and wraps around
+// (default form only: the order in which a bin's entries are added is free there) -- and tickets >= nb for nothing
+// (first = s1: loads clamped, adds skipped).
 struct SbBin { uint32_t s0, s1, nb, off; };
 template <bool WIDE>
 __device__ __forceinline__ void sb_stream(SbStream& s, uint32_t t, const SbBin bn, uint32_t lane,
@@ -189,37 +210,11 @@ __device__ __forceinline__ void sb_stream(SbStream& s, uint32_t t, const SbBin b
     for (int u = 0; u < SB_DEPTH; ++u) {
         const uint32_t sc = min(s.first + u, s1 - 1u);
         const uint64_t q = (uint64_t)sc * SB_STEP + 2u * lane;
-#ifdef SPMV_SB_STREAM_PLAIN     // tuning: default cache policy for the entry stream
-        s.v[u] = *(const dbl2*)(val + q);
-        s.c[u] = *(const u32x2*)(cr + q);
-#else
         s.v[u] = __builtin_nontemporal_load((const dbl2*)(val + q));
         s.c[u] = __builtin_nontemporal_load((const u32x2*)(cr + q));
-#endif
         if (WIDE) { s.r[u] = __builtin_nontemporal_load((const u16x2*)(lrowW + q)); s.base[u] = 0; }
         else      { s.base[u] = stepBase[sc]; s.r[u] = u16x2{0, 0}; }
     }
-}
-
-#ifndef SPMV_SB_GATHER
-#define SPMV_SB_GATHER 0
-#endif
-__device__ __forceinline__ double sb_ldx(const double* __restrict__ x, uint32_t c) {      // tuning: form / cache policy of the x gather
-#if SPMV_SB_GATHER == 3       // bound probe (scripts/r02_stripes_bounds.sh): no gather at all -- the stream and the LDS adds alone
-    return 1.0 + (double)(c & 8u);
-#elif SPMV_SB_GATHER == 1
-    return __builtin_nontemporal_load(x + c);
-#elif SPMV_SB_GATHER == 2
-    return __hip_atomic_load(x + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#elif SPMV_SB_GATHER == 4     // buffer_load_dwordx2 with a 32-bit byte offset per lane (x < 4 GiB)
-    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, 0xFFFFFFFFu, 0x00020000);
-    const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rs, c << 3, 0, 0);
-    return __longlong_as_double(((unsigned long long)v.y << 32) | v.x);
-#elif SPMV_SB_GATHER == 5     // global_load_dwordx2 with a scalar base and a 32-bit byte offset per lane (x < 4 GiB)
-    return *(const double*)((const char*)x + (uint32_t)(c << 3));
-#else
-    return x[c];
-#endif
 }
 
 template <bool WIDE>
@@ -228,8 +223,8 @@ __device__ __forceinline__ void sb_gather(SbGather& g, const SbStream& s, const 
     for (int u = 0; u < SB_DEPTH; ++u) {
         const uint32_t c0 = WIDE ? s.c[u].x : s.base[u] + (s.c[u].x >> SB_ROWBITS);
         const uint32_t c1 = WIDE ? s.c[u].y : s.base[u] + (s.c[u].y >> SB_ROWBITS);
-        g.x0[u] = sb_ldx(x, c0);
-        g.x1[u] = sb_ldx(x, c1);
+        g.x0[u] = x[c0];
+        g.x1[u] = x[c1];
     }
 }
 
@@ -240,15 +235,8 @@ __device__ __forceinline__ void sb_add(double* yb, const SbStream& s, const SbGa
         const uint32_t r0 = WIDE ? s.r[u].x : s.c[u].x & SB_NONE;
         const uint32_t r1 = WIDE ? s.r[u].y : s.c[u].y & SB_NONE;
         if (s.first + u < s1) {                      // wavefront-uniform
-#ifdef SPMV_SB_NOADD          // bound probe: the stream and the gathers alone (products summed per lane, one LDS add per step)
-            double t = 0.0;
-            if (r0 != SB_NONE) t += s.v[u].x * g.x0[u];
-            if (r1 != SB_NONE) t += s.v[u].y * g.x1[u];
-            if (t == 1.2345e300) atomicAdd(&yb[r0 % 64], t);
-#else
-            if (r0 != SB_NONE) atomicAdd(&yb[r0], s.v[u].x * g.x0[u]);
-            if (r1 != SB_NONE) atomicAdd(&yb[r1], s.v[u].y * g.x1[u]);
-#endif
+            if (r0 != SB_NONE) atomicAdd(&yb[r0], s.v[u].x * g.x0[u]);      // entries e = 0..63 of the step, then
+            if (r1 != SB_NONE) atomicAdd(&yb[r1], s.v[u].y * g.x1[u]);      // e = 64..127: ascending columns
         }
     }
 }
@@ -268,15 +256,9 @@ __device__ __forceinline__ uint32_t sb_ticket(uint32_t* ctr, uint32_t lane) {
 // workgroup in a tight pack gathers no faster, because the gather is bounded by the lines a CU's L1 can have in
 // flight to L2 (~0.27-0.38 lines per clock and CU here and in scripts/microbench_gather.hip), not by L2 misses.
 
-#ifdef SPMV_SB_DEBUG          // tuning builds only: per-bin placement and progress stamps (100 MHz clock)
-__device__ uint64_t sb_dbg[8 * 8192];
-__device__ __forceinline__ uint64_t sb_now() { return __builtin_amdgcn_s_memrealtime(); }
-#define SB_STAMP(slot) do { if (bin < 8192) sb_dbg[bin * 8 + (slot)] = sb_now(); } while (0)
-#endif
-
-template <bool WIDE>
+template <bool WIDE, bool DET>
 __global__ __launch_bounds__(SB_THREADS) void sb_spmv_kernel(
-    uint32_t B, const uint32_t* __restrict__ binRow, const uint32_t* __restrict__ binStep,
+    uint32_t B, const uint32_t* __restrict__ binRow, const uint32_t* __restrict__ subStep,
     const double* __restrict__ val, const uint32_t* __restrict__ cr, const uint16_t* __restrict__ lrowW,
     const uint32_t* __restrict__ stepBase, const double* __restrict__ x, double* __restrict__ y, uint32_t ldsRows, uint32_t spread) {
     extern __shared__ double yb[];                  // ldsRows doubles (rows of the highest bin), then the ticket counter
@@ -286,51 +268,38 @@ __global__ __launch_bounds__(SB_THREADS) void sb_spmv_kernel(
     // workgroup could share the CU anyway, and a bin starts the moment the previous one is stored)
     for (uint64_t bin = lin_block(); bin < B; bin += (uint64_t)gridDim.x * gridDim.y) {
         const uint32_t row0 = binRow[bin], R = binRow[bin + 1] - row0;
-        const uint32_t s0 = binStep[bin], s1 = binStep[bin + 1];
-#ifdef SPMV_SB_DEBUG
-        if (threadIdx.x == 0 && bin < 8192) {
-            uint32_t xcc, hwid;
-            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
-            sb_dbg[bin * 8 + 0] = (uint64_t)xcc << 32 | hwid;
-            SB_STAMP(1);
-        }
-#endif
         SbStream a, b, c, d;
         SbGather g0, g1;
+        SbBin bn;
+        uint32_t mine = 3;                           // DET: this wavefront's next batch
+        if (DET) {                                   // this wavefront's own sub-stream, from its first batch on
+            bn.s0 = subStep[bin * SB_WAVES + wave]; bn.s1 = subStep[bin * SB_WAVES + wave + 1];
+            bn.off = 0;
+        } else {
+            bn.s0 = subStep[bin]; bn.s1 = subStep[bin + 1];
+        }
+        bn.nb = (bn.s1 - bn.s0 + SB_DEPTH - 1) / SB_DEPTH;
         // where this workgroup starts its sweep: the (up to) 32 workgroups of an XCD -- workgroups are dealt round-robin
         // to the 8 XCDs -- are spread over `spread`/1024 of the sweep
-        SbBin bn;
-        bn.s0 = s0; bn.s1 = s1;
-        bn.nb = (s1 - s0 + SB_DEPTH - 1) / SB_DEPTH;
-        bn.off = (uint32_t)(((uint64_t)((lin_block() / 8) % 32) * bn.nb * spread) >> 15);
-        if (s1 > s0) {                               // first three batches: tickets wave, wave + W, wave + 2 W; moving before the bin is zeroed
-            sb_stream<WIDE>(a, wave, bn, lane, val, cr, lrowW, stepBase);
-            sb_stream<WIDE>(b, wave + SB_WAVES, bn, lane, val, cr, lrowW, stepBase);
-            sb_stream<WIDE>(c, wave + 2 * SB_WAVES, bn, lane, val, cr, lrowW, stepBase);
+        if (!DET) bn.off = (uint32_t)(((uint64_t)((lin_block() / 8) % 32) * bn.nb * spread) >> 15);
+        const uint32_t s1 = bn.s1;
+        const bool any = s1 > bn.s0;                 // uniform per workgroup (default form) / per wavefront (deterministic form)
+        if (any) {                                   // first three batches; moving before the bin is zeroed
+            sb_stream<WIDE>(a, DET ? 0u : wave, bn, lane, val, cr, lrowW, stepBase);
+            sb_stream<WIDE>(b, DET ? 1u : wave + SB_WAVES, bn, lane, val, cr, lrowW, stepBase);
+            sb_stream<WIDE>(c, DET ? 2u : wave + 2 * SB_WAVES, bn, lane, val, cr, lrowW, stepBase);
         }
         for (uint32_t k = threadIdx.x; k < R; k += SB_THREADS) yb[k] = 0.0;
-        if (threadIdx.x == 0) *ctr = 3 * SB_WAVES;
+        if (!DET && threadIdx.x == 0) *ctr = 3 * SB_WAVES;
         __syncthreads();
-        if (s1 > s0) {
+        if (any) {
             sb_gather<WIDE>(g0, a, x);
-#ifdef SPMV_SB_DEBUG
-            const uint32_t quarter = (s1 - s0) / 4;
-            uint32_t nextMark = 1;
-            // progress = tickets handed out so far (the sweep starts anywhere in the bin and wraps around)
-#define SB_PROGRESS(S) do { const uint32_t done_ = (uint32_t)__builtin_amdgcn_readfirstlane((int)*(volatile uint32_t*)ctr) * SB_DEPTH;   \
-                            if (lane == 0 && nextMark < 4 && done_ >= nextMark * quarter) { SB_STAMP(1 + nextMark); }                    \
-                            while (nextMark < 4 && done_ >= nextMark * quarter) ++nextMark; } while (0)
-#else
-#define SB_PROGRESS(S) do { } while (0)
-#endif
             // one stage: CUR is added, NXT gathered, FAR (the set CUR's predecessor freed) streamed with a fresh ticket
-#define SB_STAGE(CUR, NXT, FAR, GC, GN)                                                            \
-            if (CUR.first >= s1) break;                                                            \
-            sb_gather<WIDE>(GN, NXT, x);                                                           \
-            sb_stream<WIDE>(FAR, sb_ticket(ctr, lane), bn, lane, val, cr, lrowW, stepBase);        \
-            sb_add<WIDE>(yb, CUR, GC, s1);                                                         \
-            SB_PROGRESS(CUR);
+#define SB_STAGE(CUR, NXT, FAR, GC, GN)                                                                          \
+            if (CUR.first >= s1) break;                                                                          \
+            sb_gather<WIDE>(GN, NXT, x);                                                                         \
+            sb_stream<WIDE>(FAR, DET ? mine++ : sb_ticket(ctr, lane), bn, lane, val, cr, lrowW, stepBase);       \
+            sb_add<WIDE>(yb, CUR, GC, s1);
             for (;;) {
                 SB_STAGE(a, b, d, g0, g1)
                 SB_STAGE(b, c, a, g1, g0)
@@ -338,12 +307,8 @@ __global__ __launch_bounds__(SB_THREADS) void sb_spmv_kernel(
                 SB_STAGE(d, a, c, g1, g0)
             }
 #undef SB_STAGE
-#undef SB_PROGRESS
         }
         __syncthreads();
-#ifdef SPMV_SB_DEBUG
-        if (threadIdx.x == 0) SB_STAMP(5);
-#endif
         for (uint32_t k = threadIdx.x; k < R; k += SB_THREADS) y[(uint64_t)row0 + k] = yb[k];
         __syncthreads();                             // the next bin zeroes yb
     }
@@ -358,8 +323,8 @@ struct TempBuf {
     template <typename T> T* as() { return static_cast<T*>(p); }
 };
 
-// Bins: consecutive rows, (nearly) equal entry counts, at most SB_R_MAX rows.  Equal counts are what keeps the
-// workgroups of one XCD at the same place of their column sweeps; the bin count is a multiple of the CU count
+// Bins: consecutive rows, (nearly) equal entry counts, at most rMax rows.  Equal counts are what keeps the
+// workgroups of one XCD at the same place of their column sweeps; the bin count is a multiple of the workgroup count
 // (one workgroup per CU at a time: bins run in rounds) once the matrix is large enough for a full round.
 bool planBins(const std::vector<uint64_t>& irp, uint64_t M, uint32_t rMax, uint32_t cus, std::vector<uint32_t>& binRow) {
     const uint64_t nnz = irp[M];
@@ -367,7 +332,7 @@ bool planBins(const std::vector<uint64_t>& irp, uint64_t M, uint32_t rMax, uint3
     B = std::max<uint64_t>(1, std::min<uint64_t>(B, M));
     if (B > cus) B = (B + cus - 1) / cus * cus;
     if (B > M) B = M;
-    if (B >= (1ull << 31)) return false;
+    if (B >= (1ull << 31) / SB_WAVES) return false;
     binRow.assign(B + 1, 0);
     uint64_t cur = 0;
     for (uint64_t b = 0; b < B; ++b) {
@@ -390,27 +355,8 @@ bool planBins(const std::vector<uint64_t>& irp, uint64_t M, uint32_t rMax, uint3
     return cur == M;
 }
 
-}  // namespace
-
-void freeStripes(StripeFormat* f) {
-    if (!f) return;
-    (void)hipFree(f->val); (void)hipFree(f->cr); (void)hipFree(f->lrowW); (void)hipFree(f->stepBase);
-    (void)hipFree(f->binRow); (void)hipFree(f->binStep);
-    delete f;
-}
-
-size_t stripesBytes(const DevMat* d) { return d->stripes ? d->stripes->bytes : 0; }
-
-void stripesShape(const DevMat* d, uint32_t* bins, uint32_t* rowsPerBin, int* wide, double* buildMs) {
-    const StripeFormat* f = d->stripes;
-    if (bins) *bins = f ? f->B : 0;
-    if (rowsPerBin) *rowsPerBin = f ? f->R : 0;
-    if (wide) *wide = f ? (f->wide ? 1 : 0) : 0;
-    if (buildMs) *buildMs = f ? f->buildMs : 0.0;
-}
-
-static int fillFormat(StripeFormat* f, bool wide, uint64_t nnz, unsigned colBits, const uint64_t* skeys, const uint32_t* perm,
-                      const uint32_t* rowOf, const double* AS, const uint64_t* dBinStart, uint32_t* dOverflow) {
+int fillFormat(StripeFormat* f, bool wide, uint64_t nnz, unsigned colBits, const uint64_t* skeys, const uint32_t* perm,
+               const uint32_t* rowOf, const double* AS, const uint64_t* dStart, uint32_t* dOverflow) {
     const uint64_t cells = f->nSteps * SB_STEP;
     f->wide = wide;
     (void)hipFree(f->cr); (void)hipFree(f->lrowW); (void)hipFree(f->stepBase);
@@ -432,23 +378,59 @@ static int fillFormat(StripeFormat* f, bool wide, uint64_t nnz, unsigned colBits
     }
     SB_TRY(hipMemsetAsync(dOverflow, 0, 4, nullptr));
     if (wide)
-        hipLaunchKernelGGL(sb_scatter_kernel<true>, grid2d((nnz + 255) / 256, 256), dim3(256), 0, nullptr, nnz, colBits, skeys, perm, rowOf, AS,
-                           f->binRow, dBinStart, f->binStep, f->val, f->cr, f->lrowW, f->stepBase, dOverflow);
+        hipLaunchKernelGGL(sb_scatter_kernel<true>, grid2d((nnz + 255) / 256, 256), dim3(256), 0, nullptr, nnz, colBits, f->subs, skeys, perm, rowOf, AS,
+                           f->binRow, dStart, f->subStep, f->val, f->cr, f->lrowW, f->stepBase, dOverflow);
     else
-        hipLaunchKernelGGL(sb_scatter_kernel<false>, grid2d((nnz + 255) / 256, 256), dim3(256), 0, nullptr, nnz, colBits, skeys, perm, rowOf, AS,
-                           f->binRow, dBinStart, f->binStep, f->val, f->cr, f->lrowW, f->stepBase, dOverflow);
+        hipLaunchKernelGGL(sb_scatter_kernel<false>, grid2d((nnz + 255) / 256, 256), dim3(256), 0, nullptr, nnz, colBits, f->subs, skeys, perm, rowOf, AS,
+                           f->binRow, dStart, f->subStep, f->val, f->cr, f->lrowW, f->stepBase, dOverflow);
     SB_TRY(hipGetLastError());
     return EXIT_SUCCESS;
 }
 
-int buildStripes(DevMat* d) {
-    if (d->stripes) return EXIT_SUCCESS;
+template <bool WIDE, bool DET>
+void launchSpmv(const StripeFormat* f, const double* x, double* y, hipStream_t stream) {
+    hipLaunchKernelGGL((sb_spmv_kernel<WIDE, DET>), dim3(f->grid), dim3(SB_THREADS), (size_t)8 * f->R + 16, stream, f->B, f->binRow, f->subStep,
+                       f->val, f->cr, f->lrowW, f->stepBase, x, y, f->R, f->spread);
+}
+
+}  // namespace
+
+void freeStripes(StripeFormat* f) {
+    if (!f) return;
+    (void)hipFree(f->val); (void)hipFree(f->cr); (void)hipFree(f->lrowW); (void)hipFree(f->stepBase);
+    (void)hipFree(f->binRow); (void)hipFree(f->subStep);
+    delete f;
+}
+
+size_t stripesBytes(const DevMat* d) { return d->stripes ? d->stripes->bytes : 0; }
+
+void stripesInfo(const DevMat* d, spmvStripesInfo* out) {
+    memset(out, 0, sizeof *out);
+    const StripeFormat* f = d->stripes;
+    if (!f) return;
+    out->nBins = f->B; out->rowsPerBin = f->R; out->grid = f->grid; out->spread = f->spread;
+    out->wide = f->wide ? 1 : 0; out->deterministic = f->det ? 1 : 0; out->buildMs = f->buildMs; out->bytes = f->bytes;
+}
+
+// `opts` == nullptr: automatic format, kept if one exists.  Explicit options: an existing format is replaced.
+int buildStripes(DevMat* d, const spmvStripesOpts* opts) {
+    if (d->stripes && !opts) return EXIT_SUCCESS;
     if (d->kind != Kind::CSR) return EXIT_FAILURE;
+    const spmvStripesOpts o = opts ? *opts : spmvStripesOpts{0, 0, -1, -1, 0};
     const uint64_t nnz = d->NZ, M = d->M, N = d->N;
     if (nnz >= IRP32_LIMIT || nnz == 0 || M == 0) {
         fprintf(stderr, "libspmvhip: stripes: nnz = %lu unsupported (needs 0 < nnz < 2^32)\n", (unsigned long)nnz);
         return EXIT_FAILURE;
     }
+    int dev = 0, cusDev = 0;                         // one workgroup per CU of the CURRENT device (a process may drive several)
+    SB_TRY(hipGetDevice(&dev));
+    SB_TRY(hipDeviceGetAttribute(&cusDev, hipDeviceAttributeMultiprocessorCount, dev));
+    cusDev = std::max(1, cusDev);
+    if (o.rowsPerBin > SB_R_MAX || o.grid > (unsigned)cusDev || o.spread < -1 || o.spread > 1024) {
+        fprintf(stderr, "libspmvhip: stripes: options out of range (rowsPerBin 0..%u, grid 0..%d, spread -1..1024)\n", SB_R_MAX, cusDev);
+        return EXIT_FAILURE;
+    }
+    if (d->stripes) { freeStripes(d->stripes); d->stripes = nullptr; }
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     SB_TRY(hipEventCreate(&ev0));
     SB_TRY(hipEventCreate(&ev1));
@@ -463,80 +445,85 @@ int buildStripes(DevMat* d) {
         SB_TRY(hipMemcpy(tmp.data(), d->IRP, (M + 1) * 4, hipMemcpyDeviceToHost));
         for (uint64_t i = 0; i <= M; ++i) irp[i] = tmp[i];
     }
-    uint32_t rMax = SB_R_MAX;
-    if (const char* e = getenv("SPMV_SB_ROWS")) { const int v = atoi(e); if (v >= 1 && v <= (int)SB_R_MAX) rMax = (uint32_t)v; }     // tuning only
+    const uint32_t rMax = o.rowsPerBin ? o.rowsPerBin : SB_R_MAX;
+    const uint32_t cus = o.grid ? o.grid : (uint32_t)cusDev;          // workgroups that will walk the bins: the bin count is a multiple of it
     std::vector<uint32_t> binRow;
-    uint32_t cus = SB_CUS;                           // workgroups that will walk the bins (one per CU): the bin count is a multiple of it
-    if (const char* e = getenv("SPMV_SB_GRID")) { const int v = atoi(e); if (v >= 1 && v <= (int)SB_CUS) cus = (uint32_t)v; }         // tuning only
     if (!planBins(irp, M, rMax, cus, binRow)) { fprintf(stderr, "libspmvhip: stripes: cannot cut %lu rows into bins\n", (unsigned long)M); return EXIT_FAILURE; }
-    const uint32_t B = (uint32_t)binRow.size() - 1;
-    std::vector<uint64_t> binStart(B + 1);
-    std::vector<uint32_t> binStep(B + 1);
-    uint64_t steps = 0;
-    uint32_t R = 0;
-    for (uint32_t b = 0; b < B; ++b) {
-        binStart[b] = irp[binRow[b]];
-        binStep[b] = (uint32_t)steps;
-        steps += (irp[binRow[b + 1]] - irp[binRow[b]] + SB_STEP - 1) / SB_STEP;
-        R = std::max(R, binRow[b + 1] - binRow[b]);
-    }
-    binStart[B] = nnz;
-    if (steps >= (1ull << 32) - (1u << 16)) { fprintf(stderr, "libspmvhip: stripes: too many steps\n"); return EXIT_FAILURE; }
-    binStep[B] = (uint32_t)steps;
     { std::vector<uint64_t>().swap(irp); }
+    const uint32_t B = (uint32_t)binRow.size() - 1;
+    uint32_t R = 0;
+    for (uint32_t b = 0; b < B; ++b) R = std::max(R, binRow[b + 1] - binRow[b]);
 
     StripeFormat* f = new StripeFormat;
-    f->B = B; f->R = R; f->nnz = nnz; f->nSteps = steps;
+    f->opts = o;
+    f->det = o.deterministic != 0;
+    f->subs = f->det ? SB_WAVES : 1;
+    f->B = B; f->R = R; f->nnz = nnz;
+    f->grid = std::min<uint32_t>(B, cus);
+    f->spread = f->det ? 0u : o.spread >= 0 ? (uint32_t)o.spread : SB_SPREAD;
+    const uint64_t nGroups = (uint64_t)B * f->subs;
     auto fail = [&](const char* what) { fprintf(stderr, "libspmvhip: stripes: %s failed\n", what); freeStripes(f); return EXIT_FAILURE; };
-    TempBuf keys, keysOut, idx, perm, rowOf, sortTmp, dBinStart, dOverflow;
-    if (hipMalloc(&f->binRow, ((size_t)B + 1) * 4) || hipMalloc(&f->binStep, ((size_t)B + 1) * 4) || dBinStart.alloc(((size_t)B + 1) * 8) ||
+    TempBuf keys, keysOut, idx, perm, rowOf, sortTmp, dStart, dOverflow;
+    if (hipMalloc(&f->binRow, ((size_t)B + 1) * 4) || hipMalloc(&f->subStep, ((size_t)nGroups + 1) * 4) || dStart.alloc(((size_t)nGroups + 1) * 8) ||
         dOverflow.alloc(4))
         return fail("table allocation");
-    if (hipMemcpy(f->binRow, binRow.data(), ((size_t)B + 1) * 4, hipMemcpyHostToDevice) ||
-        hipMemcpy(f->binStep, binStep.data(), ((size_t)B + 1) * 4, hipMemcpyHostToDevice) ||
-        hipMemcpy(dBinStart.p, binStart.data(), ((size_t)B + 1) * 8, hipMemcpyHostToDevice))
-        return fail("table upload");
+    if (hipMemcpy(f->binRow, binRow.data(), ((size_t)B + 1) * 4, hipMemcpyHostToDevice)) return fail("table upload");
     if (keys.alloc(nnz * 8) || keysOut.alloc(nnz * 8) || idx.alloc(nnz * 4) || perm.alloc(nnz * 4) || rowOf.alloc(nnz * 4))
         return fail("temporary allocation");
 
-    unsigned colBits = 1, binBits = 1;
+    unsigned colBits = 1, groupBits = 1;
     while (colBits < 32 && (1ull << colBits) < N) ++colBits;
-    while ((1ull << binBits) < B) ++binBits;
+    while ((1ull << groupBits) < nGroups) ++groupBits;
     if (d->irpBytes == 4)
         hipLaunchKernelGGL((sb_keys_kernel<uint32_t>), grid2d((M + 3) / 4, 256), dim3(256), 0, nullptr, M, static_cast<const uint32_t*>(d->IRP), d->JA,
-                           f->binRow, B, colBits, keys.as<uint64_t>(), idx.as<uint32_t>(), rowOf.as<uint32_t>());
+                           f->binRow, B, f->subs, colBits, keys.as<uint64_t>(), idx.as<uint32_t>(), rowOf.as<uint32_t>());
     else
         hipLaunchKernelGGL((sb_keys_kernel<uint64_t>), grid2d((M + 3) / 4, 256), dim3(256), 0, nullptr, M, static_cast<const uint64_t*>(d->IRP), d->JA,
-                           f->binRow, B, colBits, keys.as<uint64_t>(), idx.as<uint32_t>(), rowOf.as<uint32_t>());
+                           f->binRow, B, f->subs, colBits, keys.as<uint64_t>(), idx.as<uint32_t>(), rowOf.as<uint32_t>());
     if (hipGetLastError() != hipSuccess) return fail("key kernel");
     size_t tmpBytes = 0;
     if (rocprim::radix_sort_pairs(nullptr, tmpBytes, keys.as<uint64_t>(), keysOut.as<uint64_t>(), idx.as<uint32_t>(), perm.as<uint32_t>(),
-                                  (size_t)nnz, 0, colBits + binBits, (hipStream_t) nullptr) != hipSuccess || sortTmp.alloc(tmpBytes))
+                                  (size_t)nnz, 0, colBits + groupBits, (hipStream_t) nullptr) != hipSuccess || sortTmp.alloc(tmpBytes))
         return fail("sort workspace");
     if (rocprim::radix_sort_pairs(sortTmp.p, tmpBytes, keys.as<uint64_t>(), keysOut.as<uint64_t>(), idx.as<uint32_t>(), perm.as<uint32_t>(),
-                                  (size_t)nnz, 0, colBits + binBits, (hipStream_t) nullptr) != hipSuccess)
+                                  (size_t)nnz, 0, colBits + groupBits, (hipStream_t) nullptr) != hipSuccess)
         return fail("sort");
 
-    bool wide = false;
-    if (const char* e = getenv("SPMV_SB_WIDE")) wide = atoi(e) != 0;                                   // tuning / tests only
+    // where every sub-stream starts in the sorted order -> its first step (each sub-stream is padded to whole steps)
+    hipLaunchKernelGGL(sb_bounds_kernel, grid2d((nnz + 255) / 256, 256), dim3(256), 0, nullptr, nnz, colBits, keysOut.as<uint64_t>(), nGroups,
+                       dStart.as<uint64_t>());
+    if (hipGetLastError() != hipSuccess) return fail("bounds kernel");
+    std::vector<uint64_t> start(nGroups + 1);
+    if (hipMemcpy(start.data(), dStart.p, (nGroups + 1) * 8, hipMemcpyDeviceToHost) != hipSuccess) return fail("bounds download");
+    std::vector<uint32_t> subStep(nGroups + 1);
+    uint64_t steps = 0;
+    for (uint64_t g = 0; g < nGroups; ++g) {
+        subStep[g] = (uint32_t)steps;
+        steps += (start[g + 1] - start[g] + SB_STEP - 1) / SB_STEP;
+    }
+    if (steps >= (1ull << 32) - (1u << 16)) return fail("step count (too many steps)");
+    subStep[nGroups] = (uint32_t)steps;
+    f->nSteps = steps;
+    if (hipMemcpy(f->subStep, subStep.data(), (nGroups + 1) * 4, hipMemcpyHostToDevice) != hipSuccess) return fail("table upload");
+
+    bool wide = o.wide > 0;
     for (int attempt = 0; attempt < 2; ++attempt) {
         if (fillFormat(f, wide, nnz, colBits, keysOut.as<uint64_t>(), perm.as<uint32_t>(), rowOf.as<uint32_t>(), d->AS,
-                       dBinStart.as<uint64_t>(), dOverflow.as<uint32_t>()))
+                       dStart.as<uint64_t>(), dOverflow.as<uint32_t>()))
             return fail("scatter");
         uint32_t ovf = 0;
         if (hipMemcpy(&ovf, dOverflow.p, 4, hipMemcpyDeviceToHost) != hipSuccess) return fail("overflow flag");
         if (!ovf || wide) break;
         wide = true;                                  // some step spans >= 2^17 columns: 32-bit columns + 16-bit rows
     }
-    static bool attrSet = false;
-    if (!attrSet) {
-        if (hipFuncSetAttribute((const void*)sb_spmv_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, SB_R_MAX * 8 + 16) ||
-            hipFuncSetAttribute((const void*)sb_spmv_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, SB_R_MAX * 8 + 16))
-            return fail("kernel attribute");
-        attrSet = true;
-    }
+    // (set at every build: the attribute belongs to the current device, and a process may drive several)
+    if (hipFuncSetAttribute((const void*)sb_spmv_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, SB_R_MAX * 8 + 16) ||
+        hipFuncSetAttribute((const void*)sb_spmv_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, SB_R_MAX * 8 + 16) ||
+        hipFuncSetAttribute((const void*)sb_spmv_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, SB_R_MAX * 8 + 16) ||
+        hipFuncSetAttribute((const void*)sb_spmv_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, SB_R_MAX * 8 + 16))
+        return fail("kernel attribute");
     const uint64_t cells = steps * SB_STEP;
-    f->bytes = cells * (f->wide ? 14 : 12) + (f->wide ? 0 : steps * 4) + ((size_t)B + 1) * 8;
+    f->bytes = cells * (f->wide ? 14 : 12) + (f->wide ? 0 : steps * 4) + ((size_t)B + 1) * 4 + ((size_t)nGroups + 1) * 4;
     if (hipEventRecord(ev1, nullptr) != hipSuccess || hipEventSynchronize(ev1) != hipSuccess) return fail("synchronise");
     float ms = 0;
     (void)hipEventElapsedTime(&ms, ev0, ev1);
@@ -545,39 +532,19 @@ int buildStripes(DevMat* d) {
     return EXIT_SUCCESS;
 }
 
-int enqueueStripes(DevMat* d, const double* x, double* y, hipStream_t stream) {
-    StripeFormat* f = d->stripes;
+// One persistent workgroup per CU (its bin of y fills the LDS).  Start of the sweeps: the workgroups of one XCD begin
+// SB_SPREAD/1024 of the bin apart in all (0.6 %, wrapping around).  Started together they all ask L2 for the same lines in
+// the same microsecond and every one of them waits for the fabric; a few microseconds apart the first to arrive pays and
+// the rest hit: the first quarter of a bin 113 instead of 123 us and the bin 404 instead of 417 us on c3.  Past ~2 % the
+// tail of the pack outlives its lines in the 4 MiB L2 (c3: 6.4 % 1.05 ms, 100 % 2.96 ms; profiles/r02_stripes_spread.log).
+int enqueueStripes(DevMat* d, const double* x, double* y, hipStream_t stream, dim3* grid, dim3* block) {
+    const StripeFormat* f = d->stripes;
     if (!f) return EXIT_FAILURE;
-    static int cus = 0;                              // one workgroup per CU (its bin of y fills the LDS): the persistent grid
-    if (!cus) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return EXIT_FAILURE;
-        cus = std::max(1, prop.multiProcessorCount);
-    }
-    uint32_t grid = std::min<uint32_t>(f->B, (uint32_t)cus);
-    if (const char* e = getenv("SPMV_SB_GRID")) { const int v = atoi(e); if (v >= 1 && v <= cus) grid = std::min<uint32_t>(f->B, (uint32_t)v); }   // tuning only
-    const size_t lds = (size_t)8 * f->R + 16;
-    // Start of the sweeps: the workgroups of one XCD begin SB_SPREAD/1024 of the bin apart in all (0.6 %, wrapping around).
-    // Started together they all ask L2 for the same lines in the same microsecond and every one of them waits for the
-    // fabric; a few microseconds apart the first to arrive pays and the rest hit: the first quarter of a bin 113 instead
-    // of 123 us and the bin 404 instead of 417 us on c3 (scripts/stripes_outliers.py).  Past ~2 % the tail of the pack
-    // outlives its lines in the 4 MiB L2 (c3: 6.4 % 1.05 ms, 100 % 2.96 ms; profiles/r02_stripes_spread.log).
-    uint32_t spread = SB_SPREAD;
-    if (const char* e = getenv("SPMV_SB_SPREAD")) { const int v = atoi(e); if (v >= 0 && v <= 1024) spread = (uint32_t)v; }          // tuning only
-    if (f->wide)
-        hipLaunchKernelGGL(sb_spmv_kernel<true>, dim3(grid), dim3(SB_THREADS), lds, stream, f->B, f->binRow, f->binStep, f->val, f->cr,
-                           f->lrowW, f->stepBase, x, y, f->R, spread);
-    else
-        hipLaunchKernelGGL(sb_spmv_kernel<false>, dim3(grid), dim3(SB_THREADS), lds, stream, f->B, f->binRow, f->binStep, f->val, f->cr,
-                           f->lrowW, f->stepBase, x, y, f->R, spread);
+    if (grid) *grid = dim3(f->grid);
+    if (block) *block = dim3(SB_THREADS);
+    if (f->wide) { if (f->det) launchSpmv<true, true>(f, x, y, stream); else launchSpmv<true, false>(f, x, y, stream); }
+    else         { if (f->det) launchSpmv<false, true>(f, x, y, stream); else launchSpmv<false, false>(f, x, y, stream); }
     return hipGetLastError() == hipSuccess ? EXIT_SUCCESS : EXIT_FAILURE;
 }
 
 }  // namespace spmvhip
-
-#ifdef SPMV_SB_DEBUG
-extern "C" int spmvHipStripesDebugDump(uint64_t* host, size_t words) {
-    return hipMemcpyFromSymbol(host, HIP_SYMBOL(spmvhip::sb_dbg), std::min<size_t>(words, 8 * 8192) * 8) == hipSuccess ? 0 : 1;
-}
-#endif

@@ -48,13 +48,10 @@
 
 namespace spmvhip {
 
-#ifndef SPMV_PB_COLS
-#define SPMV_PB_COLS 16384
-#endif
-constexpr uint32_t PB_C       = SPMV_PB_COLS;       // columns per slice: 16 Ki = 128 KiB of x in LDS (19 Ki = 152 KiB measured no faster: c3 1.075 vs 1.050 ms, c5 equal)
+constexpr uint32_t PB_C       = 16384;              // columns per slice: 16 Ki = 128 KiB of x in LDS (19 Ki = 152 KiB measured no faster: c3 1.075 vs 1.050 ms, c5 equal)
 static_assert(PB_C % 1024 == 0 && PB_C * 8 <= 160 * 1024 && PB_C <= 65536, "slice width");
 constexpr uint32_t PB_R_MAX   = 20000;             // rows per bin: <= 156 KiB of y in LDS (160 KiB per CU on gfx950)
-constexpr uint32_t PB_CUS     = 256;               // compute units (phase 2 keeps one workgroup per CU)
+constexpr uint32_t PB_CUS_DEFAULT = 256;           // compute units when the device does not say (phase 2 keeps one workgroup per CU)
 constexpr uint32_t PB_CHUNK   = 1u << 17;           // entries of one slice handled by one phase-1 workgroup
 constexpr int      PB_THREADS = 1024;
 constexpr size_t   PB_RESIDENT_BYTES = 288ull << 20; // products up to this size stay in the 256 MiB Infinity Cache between the phases (c2, 244 MiB: 0.156 ms plain vs 0.176 ms nt stores)
@@ -96,6 +93,7 @@ struct TileFormat {
     uint32_t* ready = nullptr;                      // [B] epoch of the last step whose bin was stored (push kernel hand-off)
     uint32_t* pushFail = nullptr;                   // set by the push kernel when a flag never arrived
     uint32_t  epoch = 0;
+    uint32_t  cus = PB_CUS_DEFAULT;                 // CUs of the device the format was built on
     size_t    bytes = 0;
     spmvTilesOpts opts{0, 0, -1, 0};                // what the format was built with (0 / -1 = automatic)
     uint32_t  chunk = 0;                            // phase-1 work item size in entries actually used
@@ -212,10 +210,7 @@ __global__ __launch_bounds__(256) void pb_fill_kernel(uint32_t* p, uint64_t n, u
 typedef double   dbl2 __attribute__((ext_vector_type(2)));
 typedef uint16_t ush2 __attribute__((ext_vector_type(2)));
 
-#ifndef SPMV_P1_DEPTH
-#define SPMV_P1_DEPTH 8
-#endif
-constexpr int      P1_DEPTH = SPMV_P1_DEPTH;        // steps per batch
+constexpr int      P1_DEPTH = 8;                    // steps per batch
 constexpr uint32_t P1_STEP  = 2 * PB_THREADS;       // entries one workgroup step covers
 struct P1Regs { dbl2 a[P1_DEPTH]; ush2 c[P1_DEPTH]; };
 
@@ -225,13 +220,8 @@ __device__ __forceinline__ void p1_load(P1Regs& r, uint32_t p, uint32_t ve, cons
 #pragma unroll
     for (int u = 0; u < P1_DEPTH; ++u) {
         const uint32_t q = min(p + u * P1_STEP, ve - 2u);
-#ifdef SPMV_P1_PLAIN_LOAD   // tuning
-        r.a[u] = *(const dbl2*)(val + q);
-        r.c[u] = *(const ush2*)(lcol + q);
-#else
         r.a[u] = __builtin_nontemporal_load((const dbl2*)(val + q));
         r.c[u] = __builtin_nontemporal_load((const ush2*)(lcol + q));
-#endif
     }
 }
 
@@ -265,20 +255,15 @@ __global__ __launch_bounds__(PB_THREADS) void pb_expand_kernel(
     // Order of the first requests: the x slice BEFORE the first stream batch.  vmcnt counts in issue order, so the LDS
     // fill below waits for the slice only while the batch behind it is still in flight; with the batch first (round 1)
     // the fill waited for both (c5: 8.13-8.20 against 8.26-8.46 ms over 5 fresh processes each,
-    // profiles/r02_tiles_load_policy.log).  SPMV_P1_STREAM_FIRST restores the old order for the A/B.
+    // profiles/r02_tiles_load_policy.log).
     {
         double xv[PB_C / PB_THREADS];
-#ifdef SPMV_P1_STREAM_FIRST
-        if (vec) p1_load(cur, p, ve, val, lcol);
-#endif
 #pragma unroll
         for (uint32_t i = 0; i < PB_C / PB_THREADS; ++i) {
             const uint32_t k = threadIdx.x + i * PB_THREADS;
             xv[i] = (col0 + k < N) ? x[col0 + k] : 0.0;
         }
-#ifndef SPMV_P1_STREAM_FIRST
         if (vec) p1_load(cur, p, ve, val, lcol);
-#endif
 #pragma unroll
         for (uint32_t i = 0; i < PB_C / PB_THREADS; ++i) xs[threadIdx.x + i * PB_THREADS] = xv[i];
     }
@@ -310,10 +295,7 @@ __global__ __launch_bounds__(PB_THREADS) void pb_expand_kernel(
 // -- vmcnt is in-order -- and ran 34 % slower than the descriptor version this replaces.)
 // Two batches of P2_DEPTH steps are in flight: the loads of the next batch are issued before the LDS atomics
 // of the current one.
-#ifndef SPMV_P2_DEPTH
-#define SPMV_P2_DEPTH 8
-#endif
-constexpr int      P2_DEPTH = SPMV_P2_DEPTH;
+constexpr int      P2_DEPTH = 8;                    // steps per batch (4 / 6 / 8 / 12 equal within the noise)
 constexpr uint32_t P2_WAVES = PB_THREADS / 64;
 constexpr uint16_t P2_NONE  = 0xFFFF;               // "no entry" (local rows are < PB_R_MAX)
 constexpr uint32_t P2_RUNS_FLAG = 0x80000000u;      // in waveTile[]: this wavefront's range holds runs of equal rows
@@ -348,17 +330,9 @@ __device__ __forceinline__ void p2_fetch(P2Regs& r, P2Cursor& c, uint32_t vbase,
         // steps share the line they meet in.  Through L1 the second step hits; a non-temporal load bypasses L1 and the
         // line, already dropped by L2, comes from HBM a second time -- that was the "run-boundary" traffic of round 1
         // (phase 2 of c5: 3.19 -> 2.92 ms, the SpMV 8.49 -> 8.15 ms, medians of 6 fresh processes each;
-        // profiles/r02_tiles_load_policy.log).  SPMV_P2_NT_PROD restores the old form for the A/B.
-#ifdef SPMV_P2_NT_PROD
-        r.pv[u] = __builtin_nontemporal_load(prod + (uint32_t)(vc + d));
-#else
+        // profiles/r02_tiles_load_policy.log).  The row ids are read once: non-temporal.
         r.pv[u] = prod[(uint32_t)(vc + d)];
-#endif
-#ifdef SPMV_P2_PLAIN_ROW    // tuning
-        const uint16_t row = lrow[vc];
-#else
         const uint16_t row = __builtin_nontemporal_load(lrow + vc);
-#endif
         r.rv[u] = v < we ? row : P2_NONE;
     }
 }
@@ -407,16 +381,8 @@ __global__ __launch_bounds__(PB_THREADS) void pb_reduce_kernel(
     const uint2* __restrict__ tl, const double* __restrict__ prod, const uint16_t* __restrict__ lrow,
     double* __restrict__ y, TileDst extra, TileSignal sig) {
     extern __shared__ double yb[];                  // R doubles
-#ifdef SPMV_P2_XCD      // tuning: give every XCD a contiguous range of bins (workgroups are dealt round-robin to the 8 XCDs)
-    const uint32_t nBins = binEnd - binBegin;
-    const uint64_t i_ = lin_block();
-    const uint32_t per_ = (nBins + 7) / 8;
-    const uint64_t bin = binBegin + (i_ % 8) * per_ + i_ / 8;
-    if (i_ / 8 >= per_ || bin >= binEnd) return;
-#else
     const uint64_t bin = binBegin + lin_block();
     if (bin >= binEnd) return;
-#endif
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x / 64)), lane = threadIdx.x % 64;
     const uint32_t v0 = binPos[bin], v1 = binPos[bin + 1];
     const uint32_t sub = p2_sub(v1 - v0);
@@ -502,10 +468,7 @@ __global__ __launch_bounds__(PB_THREADS) void pb_reduce_kernel(
 typedef double dbl2_t __attribute__((ext_vector_type(2)));
 constexpr int      PUSH_THREADS = 256;
 constexpr int      PUSH_DEPTH = 8;
-#ifndef SPMV_PUSH_WGS
-#define SPMV_PUSH_WGS 64
-#endif
-constexpr uint32_t PUSH_WGS = SPMV_PUSH_WGS;
+constexpr uint32_t PUSH_WGS = 64;
 constexpr uint32_t PUSH_SPIN_LIMIT = 1u << 20;
 __global__ __launch_bounds__(PUSH_THREADS) void pb_push_kernel(
     BinMap bm, uint32_t B, uint64_t M, const uint32_t* __restrict__ ready, uint32_t epoch, const double* __restrict__ y,
@@ -636,10 +599,8 @@ static double* prodWorkspace(size_t n, bool grow) {
     (void)hipDeviceSynchronize();                   // nothing may still read the old buffer
     if (w->raw) (void)hipFree(w->raw);
     w->p = nullptr; w->raw = nullptr; w->cap = 0;
-    size_t shift = 0;                               // tuning only: placement of the products relative to the other arrays
-    if (const char* e = getenv("SPMV_PB_PROD_OFFSET")) { const long v = atol(e); if (v >= 0 && v <= (2l << 20) && v % 256 == 0) shift = (size_t)v; }
-    if (hipMalloc(&w->raw, n * sizeof(double) + shift) != hipSuccess) { w->raw = nullptr; return nullptr; }
-    w->p = reinterpret_cast<double*>(static_cast<char*>(w->raw) + shift);
+    if (hipMalloc(&w->raw, n * sizeof(double)) != hipSuccess) { w->raw = nullptr; return nullptr; }
+    w->p = static_cast<double*>(w->raw);            // (placement relative to the other arrays, 0 ... 1 MiB offsets: no effect)
     w->cap = n;
     return w->p;
 }
@@ -707,6 +668,12 @@ int buildTiles(DevMat* d, const spmvTilesOpts* opts) {
     if (S64 > 65535) { fprintf(stderr, "libspmvhip: tiles: %lu columns exceed 65535 slices\n", (unsigned long)N); return EXIT_FAILURE; }
     TileFormat* t = new TileFormat;
     struct Guard { TileFormat*& t; ~Guard() { if (t) freeTiles(t); } } guard{t};      // every early return frees the half-built format
+    {   // one workgroup per CU of the CURRENT device in phases 1 and 2: rounds are counted in units of its CU count
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0)
+            t->cus = (uint32_t)cus;
+    }
+    const uint32_t PB_CUS = t->cus;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     PB_TRY(hipEventCreate(&ev0));
     PB_TRY(hipEventCreate(&ev1));
@@ -730,11 +697,9 @@ int buildTiles(DevMat* d, const spmvTilesOpts* opts) {
         }
     }
     if (o.rowsPerBin) R = o.rowsPerBin;
-    if (const char* e = getenv("SPMV_PB_ROWS")) { const int v = atoi(e); if (v >= 64 && v <= (int)PB_R_MAX) R = (uint32_t)v; }   // tuning only
     t->bins = BinMap{};
     t->bins.c = R;
-    bool taper = o.taper != 0;
-    if (const char* e = getenv("SPMV_PB_TAPER")) taper = atoi(e) != 0;                                 // tuning only
+    const bool taper = o.taper != 0;
     if (taper && M >= (uint64_t)4 * PB_CUS * 1024) {
         // one round of quarter-height bins first and last, full-height bins (a multiple of PB_CUS of them) between
         const uint32_t low = std::max<uint32_t>(64, (R / 4 + 63) / 64 * 64);
@@ -766,8 +731,6 @@ int buildTiles(DevMat* d, const spmvTilesOpts* opts) {
         hipMalloc(&t->waveTile, (size_t)t->B * P2_WAVES * 4))
         return fail("format allocation");
     t->allocMs = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - allocT0).count();
-    if (getenv("SPMV_PB_DEBUG_ADDR"))               // tuning only
-        fprintf(stderr, "libspmvhip: tiles: val %p lcol %p lrow %p prod %p\n", (void*)t->val, (void*)t->lcol, (void*)t->lrow, (void*)prodWorkspace(nnz, false));
 
     if (d->irpBytes == 4)
         hipLaunchKernelGGL((pb_payload_kernel<uint32_t>), grid2d((M + 3) / 4, 256), dim3(256), 0, nullptr, M, static_cast<const uint32_t*>(d->IRP), d->JA, d->AS,
@@ -857,7 +820,6 @@ int buildTiles(DevMat* d, const spmvTilesOpts* opts) {
             if (cost < bestCost) { bestCost = cost; chunk = (uint32_t)std::min(16777216.0, std::ceil(avgLen / p * 1.02) + 64); }
         }
     }
-    if (const char* e = getenv("SPMV_PB_CHUNK")) { const long v = atol(e); if (v >= 4096 && v <= (1l << 24)) chunk = (uint32_t)v; }   // tuning only
     for (uint32_t s = 0; s < t->S; ++s) {
         // a slice is cut into equal pieces of at most PB_CHUNK entries (a fixed chunk size + remainder left one
         // short, fill-dominated work item per slice); inner boundaries fall on multiples of 64 entries so that
@@ -878,7 +840,7 @@ int buildTiles(DevMat* d, const spmvTilesOpts* opts) {
     // piece fetches the slice from the fabric (c5, 4 pieces: 2.6 GB of fills per SpMV); listed 8 apart -- groups of 8
     // slices, piece k of each, then piece k+1 of each -- they land on ONE XCD at almost the same time and all but the
     // first fill hit its L2.
-    if (!getenv("SPMV_PB_NO_XCD_ORDER")) {
+    {
         std::vector<uint3> ordered;
         ordered.reserve(work.size());
         size_t i = 0;
@@ -917,7 +879,6 @@ int buildTiles(DevMat* d, const spmvTilesOpts* opts) {
     // that phase 2 finds them there; larger streams bypass it (microbench_mall.hip: resident 7.0 vs 5.8 TB/s with
     // non-temporal stores; non-resident 4.9 vs 5.1-5.4)
     t->ntStore = o.ntStore >= 0 ? o.ntStore != 0 : nnz * 8 > PB_RESIDENT_BYTES;
-    if (const char* e = getenv("SPMV_PB_NTSTORE")) t->ntStore = atoi(e) != 0;                         // tuning only
     t->chunk = chunk;
     PB_TRY(hipEventRecord(ev1, nullptr));
     PB_TRY(hipEventSynchronize(ev1));

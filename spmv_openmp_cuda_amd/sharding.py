@@ -113,14 +113,22 @@ class GatherBuffers:
 def step(plan, dist, bufs, compute_group):
     """One sharded SpMV: for every group run `compute_group(g, slot_tensor)` (enqueues the kernels that
     write this rank's rows of group g into the slot), then all-gather the group asynchronously; finally
-    wait for the gathers in order and compact.  Returns bufs.y."""
-    works = []
+    wait for the gathers in order and compact.  Returns bufs.y.
+    A `compute_group` that raises on THIS rank does not strand the other ranks in their collectives: every gather of
+    the step is still issued (the slot then holds whatever it held), and the exception is re-raised afterwards."""
+    works, failure = [], None
     for g in range(plan.groups):
-        compute_group(g, bufs.slot[g])
+        if failure is None:
+            try:
+                compute_group(g, bufs.slot[g])
+            except Exception as e:                  # noqa: BLE001 -- re-raised below, after the collectives
+                failure = e
         works.append(dist.all_gather_into_tensor(bufs.ypad[g], bufs.slot[g], async_op=True))
     for g, w in enumerate(works):
         w.wait()
         bufs.compact(g)
+    if failure is not None:
+        raise failure
     return bufs.y
 
 
@@ -388,12 +396,19 @@ def search_exchange(keys, make, dist, torch, device, validate, budget_s=60.0, st
                 cand.free()
             on_resolved(i, best_key)
             continue
-        cand.poison()
-        dist.barrier()
         good = False
         try:
-            cand.step()
-            good = bool(validate(cand, ref))
+            cand.poison()
+        except Exception as e:                      # noqa: BLE001 -- agreed on below: nobody is left alone in the barrier
+            log(f"exchange candidate {key.name} could not poison y here: {e}")
+            cand_ok = False
+        else:
+            cand_ok = True
+        dist.barrier()
+        try:
+            if cand_ok:
+                cand.step()
+                good = bool(validate(cand, ref))
         except Exception as e:                      # noqa: BLE001
             log(f"exchange candidate {key.name} failed its validating step here: {e}")
         if agree(1.0 if good else 0.0, dist.ReduceOp.MIN) == 0.0:
@@ -405,11 +420,29 @@ def search_exchange(keys, make, dist, torch, device, validate, budget_s=60.0, st
             ref = cand.y.clone()
         dist.barrier()
         t0 = clock()
+        timed_ok = True
+        # A step that raises on ONE rank (a launcher returning failure, a push kernel giving up) must not leave the others
+        # waiting in a collective: the candidates' step() keep their collectives matched even then, this rank goes on
+        # through ALL the steps the others run, and the drop is agreed on afterwards.
         for _ in range(steps):
-            cand.step()
-        if hasattr(cand, "sync"):
-            cand.sync()
-        times[key.name] = agree((clock() - t0) / steps * 1e3, dist.ReduceOp.MAX)
+            try:
+                cand.step()
+            except Exception as e:                  # noqa: BLE001
+                timed_ok = False
+                log(f"exchange candidate {key.name} failed a timed step here: {e}")
+        try:
+            if hasattr(cand, "sync"):
+                cand.sync()
+        except Exception as e:                      # noqa: BLE001
+            timed_ok = False
+            log(f"exchange candidate {key.name} failed to synchronise here: {e}")
+        elapsed_ms = (clock() - t0) / steps * 1e3
+        if agree(1.0 if timed_ok else 0.0, dist.ReduceOp.MIN) == 0.0:
+            rejected[key.name] = "a timed step failed on some rank"
+            cand.free()
+            on_resolved(i, best_key)
+            continue
+        times[key.name] = agree(elapsed_ms, dist.ReduceOp.MAX)
         if best is None or times[key.name] < times[best_key.name]:
             if best is not None:
                 best.free()

@@ -100,16 +100,16 @@ def _run(api, launcher, dmat, x, rows):
 def _default_variants(api):
     """every test starts (and leaves) with the default kernel variants"""
     api.set_variant("hipSpMVRowsCSR", 1)
-    api.set_variant("hipSpMVWarpPerRowCSR", 1)
+    api.set_variant("hipSpMVWarpPerRowCSR", 2)
     yield
     api.set_variant("hipSpMVRowsCSR", 1)
-    api.set_variant("hipSpMVWarpPerRowCSR", 1)
+    api.set_variant("hipSpMVWarpPerRowCSR", 2)
 
 
 @pytest.mark.parametrize("name", list(CASES))
 @pytest.mark.parametrize("launcher,variant,exact", [
     ("hipSpMVRowsCSR", 0, True), ("hipSpMVRowsCSR", 1, True),
-    ("hipSpMVWarpPerRowCSR", 0, False), ("hipSpMVWarpPerRowCSR", 1, False),
+    ("hipSpMVWarpPerRowCSR", 0, False), ("hipSpMVWarpPerRowCSR", 1, False), ("hipSpMVWarpPerRowCSR", 2, False),
     ("hipSpMVTilesCSR", -1, False), ("hipSpMVStripesCSR", -1, False), ("hipSpMVRowsSELL", -1, False)])
 def test_csr(api, oracle, name, launcher, variant, exact):
     M, N, IRP, JA, AS = CASES[name]
@@ -130,6 +130,9 @@ def test_csr(api, oracle, name, launcher, variant, exact):
         wide = C.c_int(-1)
         assert api.lib.spmvHipStripesShape(C.byref(dmat.handle), None, None, C.byref(wide), None) == 0
         assert wide.value == (1 if name == "hyper-sparse" else 0)
+        # what spmvHipLastLaunch reports is what ran: min(bins, CUs) persistent workgroups of 256 threads
+        info = api.stripes_info(dmat)
+        assert api.last_launch() == ((info.grid, 1, 1), (256, 1, 1)) and 1 <= info.grid <= info.nBins
     dmat.free()
     assert not np.isnan(y).any(), "rows left unwritten (poison survived)"
     assert np.max(np.abs(y - y_ref), initial=0.0) <= GATE
@@ -212,12 +215,16 @@ def test_synth_device_matches_twin_and_oracle(api, oracle):
             dm.free()
 
 
-@pytest.mark.parametrize("key", ["c3", "c5"])
+@pytest.mark.parametrize("key", ["c2", "c3", "c5"])
 def test_full_size_spot_checks(api, oracle, key):
-    """BASELINE.json's full sizes (10 M / 200 M and 80 M / 1.6 G): the whole y must be
+    """BASELINE.json's full sizes (1 M x 32, 10 M / 200 M and 80 M / 1.6 G): the whole y must be
     written (no poison left) and rows at the start, middle, end and around the
     heaviest row must match the oracle.  (A launch whose blocks*threads wrapped the
-    32-bit work-item count once left most of c5 unfilled -- this is its regression test.)"""
+    32-bit work-item count once left most of c5 unfilled -- this is its regression test.)
+    hipSpMVAutoCSR runs FIRST, on the fresh handle: its choice must be the stripes kernel on c2 and c3 (x fits the
+    Infinity Cache) and the two-phase kernel on c5, and the losers must leave no format behind; hipSpMVWarpPerRowCSR in
+    its default variant must then run that same choice."""
+    import ctypes as C
     from spmv_openmp_cuda_amd import synth
     w = synth.WORKLOADS[key]
     lens = synth.row_lengths(w)
@@ -235,12 +242,15 @@ def test_full_size_spot_checks(api, oracle, key):
         # the device generator wrote the same entries
         b0, b1 = int(irp[r0]), int(irp[r1])
         ja_dev = np.empty(b1 - b0, dtype=np.uint32)
-        api.lib.spmvHipMemcpyDown(ja_dev.ctypes.data_as(__import__("ctypes").c_void_p),
-                                  dm.buffers["JA"].ptr.value + 4 * b0, 4 * (b1 - b0))
+        api.lib.spmvHipMemcpyDown(ja_dev.ctypes.data_as(C.c_void_p), dm.buffers["JA"].ptr.value + 4 * b0, 4 * (b1 - b0))
         assert np.array_equal(ja_dev, ja)
         refs.append(oracle.csr_serial_dev((irp[r0:r1 + 1] - irp[r0]).astype(np.uint32), ja, as_, x))
-    for launcher, exact in (("hipSpMVWarpPerRowCSR", False), ("hipSpMVRowsCSR", True), ("hipSpMVTilesCSR", False),
-                            ("hipSpMVStripesCSR", False), ("hipSpMVRowsSELL", False)):
+    expect = b"hipSpMVTilesCSR" if key == "c5" else b"hipSpMVStripesCSR"
+    for launcher, variant, exact in (("hipSpMVAutoCSR", -1, False), ("hipSpMVWarpPerRowCSR", 2, False), ("hipSpMVWarpPerRowCSR", 1, False),
+                                     ("hipSpMVRowsCSR", 1, True), ("hipSpMVTilesCSR", -1, False), ("hipSpMVStripesCSR", -1, False),
+                                     ("hipSpMVRowsSELL", -1, False)):
+        if variant >= 0:
+            api.set_variant(launcher, variant)
         dy.poison()
         api.spmv(launcher, dm, dx, dy)
         y = dy.down()
@@ -249,11 +259,16 @@ def test_full_size_spot_checks(api, oracle, key):
             assert np.max(np.abs(y[r0:r1] - yr)) <= GATE
             if exact:
                 assert np.array_equal(y[r0:r1], yr)
+        arrival_order = launcher in ("hipSpMVTilesCSR", "hipSpMVStripesCSR", "hipSpMVAutoCSR") or (launcher, variant) == ("hipSpMVWarpPerRowCSR", 2)
+        if launcher == "hipSpMVAutoCSR" or (launcher, variant) == ("hipSpMVWarpPerRowCSR", 2):
+            assert api.lib.spmvHipAutoChoice(C.byref(dm.handle), None) == expect
+            tb, sb = api.lib.spmvHipTilesBytes(C.byref(dm.handle)), api.lib.spmvHipStripesBytes(C.byref(dm.handle))
+            assert (tb > 0) == (expect == b"hipSpMVTilesCSR") and (sb > 0) == (expect == b"hipSpMVStripesCSR")
         # linearity (size-independent property): A(2x) == 2 A(x) exactly in binary fp
         dx2 = api.DeviceVector(w.N).up(2.0 * x)
         dy.poison()
         api.spmv(launcher, dm, dx2, dy)
-        if launcher in ("hipSpMVTilesCSR", "hipSpMVStripesCSR"):       # arrival-order sums: linear up to rounding only
+        if arrival_order:                                   # arrival-order sums: linear up to rounding only
             assert np.max(np.abs(dy.down() - 2.0 * y)) <= 1e-15
         else:
             assert np.array_equal(dy.down(), 2.0 * y)
@@ -295,7 +310,7 @@ def test_64bit_row_pointers_small(api, oracle):
     dm = api.DeviceMatrix()
     assert api.lib.spmvHipAdoptCSR(C.byref(dm.handle), M, N, JA.size, d_irp.ptr, 8, d_ja.ptr, d_as.ptr, None) == 0
     dm.keep = [d_irp, d_ja, d_as]
-    for launcher, variants, exact in (("hipSpMVRowsCSR", (0, 1), True), ("hipSpMVWarpPerRowCSR", (0, 1), False),
+    for launcher, variants, exact in (("hipSpMVRowsCSR", (0, 1), True), ("hipSpMVWarpPerRowCSR", (0, 1, 2), False),
                                       ("hipSpMVTilesCSR", (-1,), False), ("hipSpMVStripesCSR", (-1,), False),
                                       ("hipSpMVRowsSELL", (-1,), False)):
         for v in variants:
@@ -306,7 +321,7 @@ def test_64bit_row_pointers_small(api, oracle):
             if exact:
                 assert np.array_equal(y, y_ref)
     api.set_variant("hipSpMVRowsCSR", 1)
-    api.set_variant("hipSpMVWarpPerRowCSR", 1)
+    api.set_variant("hipSpMVWarpPerRowCSR", 2)
     dm.free()
 
 
@@ -405,7 +420,7 @@ def test_config_block_sizes(api, oracle):
             y = dy.down()
             assert not np.isnan(y).any() and np.max(np.abs(y - y_ref)) <= GATE, (launcher, bx)
     api.set_variant("hipSpMVRowsCSR", 1)
-    api.set_variant("hipSpMVWarpPerRowCSR", 1)
+    api.set_variant("hipSpMVWarpPerRowCSR", 2)
     for m in (dcsr, dell_t, dell):
         m.free()
 
@@ -545,19 +560,17 @@ def test_upload_rejects_decreasing_row_pointers_and_bad_transposed_columns(api):
 
 
 @pytest.mark.parametrize("name", ["irregular", "wide", "banded", "ones"])
-def test_stripes_many_small_bins(api, oracle, name, monkeypatch):
-    """The stripes kernel with bins of at most 64 rows (tuning knob SPMV_SB_ROWS): hundreds of bins on a small matrix,
+def test_stripes_many_small_bins(api, oracle, name):
+    """The stripes kernel with bins of at most 64 rows (spmvHipBuildStripesOpt): hundreds of bins on a small matrix,
     i.e. several bins per persistent workgroup, bins without entries, single-row bins holding a long row."""
-    import ctypes as C
-    monkeypatch.setenv("SPMV_SB_ROWS", "64")
     M, N, IRP, JA, AS = CASES[name]
     x = _x(np.random.default_rng(17), N)
     y_ref = oracle.csr_serial(IRP, JA, AS, x)
     dmat = api.spMatCpyCSR(api.HostCSR(M, N, IRP, JA, AS))
+    api.build_stripes(dmat, rowsPerBin=64)
     y = _run(api, "hipSpMVStripesCSR", dmat, x, M)
-    nb, rpb = C.c_uint(), C.c_uint()
-    assert api.lib.spmvHipStripesShape(C.byref(dmat.handle), C.byref(nb), C.byref(rpb), None, None) == 0
-    assert rpb.value <= 64 and nb.value >= (M + 63) // 64
+    info = api.stripes_info(dmat)
+    assert info.rowsPerBin <= 64 and info.nBins >= (M + 63) // 64 and info.buildMs > 0 and info.bytes > 0
     dmat.free()
     assert not np.isnan(y).any()
     assert np.max(np.abs(y - y_ref), initial=0.0) <= GATE
@@ -707,27 +720,77 @@ def test_fuzz_random_shapes(api, oracle, seed):
         api.lib.spmvHipSetEllRowLens(1)
 
 
-@pytest.mark.parametrize("spread,grid,rows", [(0, None, None), (1024, None, None), (1024, 3, 64), (517, 5, 200), (6, 1, 64)])
-def test_stripes_rotated_sweeps(api, oracle, spread, grid, rows, monkeypatch):
-    """The stripes kernel starts every workgroup's sweep somewhere inside the bin and wraps around (tuning knob
-    SPMV_SB_SPREAD: 1/1024ths of the bin over which one XCD's workgroups are spread).  Every entry must still be added
-    exactly once: no spread, the full bin, bins of one or two batches, and persistent grids of 1, 3 and 5 workgroups
-    (SPMV_SB_GRID) walking many bins each."""
-    monkeypatch.setenv("SPMV_SB_SPREAD", str(spread))
-    if grid:
-        monkeypatch.setenv("SPMV_SB_GRID", str(grid))
-    if rows:
-        monkeypatch.setenv("SPMV_SB_ROWS", str(rows))
+@pytest.mark.parametrize("spread,grid,rows,wide", [(0, 0, 0, -1), (1024, 0, 0, -1), (1024, 3, 64, -1), (517, 5, 200, 1), (6, 1, 64, -1)])
+def test_stripes_rotated_sweeps(api, oracle, spread, grid, rows, wide):
+    """The stripes kernel starts every workgroup's sweep somewhere inside the bin and wraps around (spmvStripesOpts.spread:
+    1/1024ths of the bin over which one XCD's workgroups are spread).  Every entry must still be added exactly once: no
+    spread, the full bin, bins of one or two batches, persistent grids of 1, 3 and 5 workgroups (opts.grid) walking many
+    bins each, and the 32-bit-column encoding forced on matrices that do not need it (opts.wide).  Options are arguments
+    of the build: an explicit build replaces the format, out-of-range options are refused, a handle built afterwards
+    without options gets the automatic format."""
     for name in ("irregular", "wide", "banded", "ones", "uniform32"):
         M, N, IRP, JA, AS = CASES[name]
         x = _x(np.random.default_rng(23), N)
         y_ref = oracle.csr_serial(IRP, JA, AS, x)
         dmat = api.spMatCpyCSR(api.HostCSR(M, N, IRP, JA, AS))
+        api.build_stripes(dmat, rowsPerBin=rows, grid=grid, spread=spread, wide=wide)
+        info = api.stripes_info(dmat)
+        assert info.spread == spread and (not grid or info.grid <= grid) and (not rows or info.rowsPerBin <= rows)
+        assert info.wide == (1 if wide == 1 else 0) and info.deterministic == 0
         y = _run(api, "hipSpMVStripesCSR", dmat, x, M)
         dmat.free()
         assert not np.isnan(y).any(), name
         assert np.max(np.abs(y - y_ref), initial=0.0) <= GATE, name
         assert tight_error(IRP, JA, AS, x, y_ref, y) <= TIGHT, name
+    M, N, IRP, JA, AS = CASES["irregular"]
+    dmat = api.spMatCpyCSR(api.HostCSR(M, N, IRP, JA, AS))
+    for bad in (dict(rowsPerBin=20001), dict(grid=100000), dict(spread=1025), dict(spread=-2)):
+        with pytest.raises(api.SpmvHipError):
+            api.build_stripes(dmat, **bad)
+    assert api.stripes_info(dmat).nBins == 0                 # a refused build leaves nothing behind
+    _run(api, "hipSpMVStripesCSR", dmat, _x(np.random.default_rng(1), N), M)
+    assert api.stripes_info(dmat).spread == 6 and api.stripes_info(dmat).rowsPerBin <= 20000
+    dmat.free()
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_stripes_deterministic_form_is_the_serial_order(api, oracle, name):
+    """spmvStripesOpts.deterministic: every row is added by ONE wavefront in ascending column order, so y is (a) the same
+    bits in every run, (b) the same bits whatever the bin layout (bins of 64, 700 or 20 000 rows; 1, 3 or all
+    workgroups), (c) the same bits when the rows are computed as three separate row blocks (the shape of a 3-rank run)
+    and (d) the bits of the serial oracle -- the columns of every row ascend in these matrices, as the reference's loader
+    guarantees (src/lib/parser.c:195-202)."""
+    M, N, IRP, JA, AS = CASES[name]
+    if JA.size == 0:
+        pytest.skip("the stripes format needs at least one entry")
+    x = _x(np.random.default_rng(29), N)
+    y_ref = oracle.csr_serial(IRP, JA, AS, x)
+    dmat = api.spMatCpyCSR(api.HostCSR(M, N, IRP, JA, AS))
+    ys = []
+    for rows, grid in ((0, 0), (64, 3), (700, 1), (0, 0)):
+        api.build_stripes(dmat, rowsPerBin=rows, grid=grid, deterministic=True)
+        assert api.stripes_info(dmat).deterministic == 1
+        for _ in range(3):
+            ys.append(_run(api, "hipSpMVStripesCSR", dmat, x, M))
+    dmat.free()
+    for y in ys:
+        assert np.array_equal(y, ys[0])
+    assert np.array_equal(ys[0], y_ref)
+    # three row blocks, as three ranks would hold them
+    cuts = [0, M // 3, 2 * M // 3, M]
+    parts = []
+    for r0, r1 in zip(cuts[:-1], cuts[1:]):
+        if r1 == r0:
+            continue
+        b0, b1 = int(IRP[r0]), int(IRP[r1])
+        if b1 == b0:
+            parts.append(np.zeros(r1 - r0))
+            continue
+        blk = api.spMatCpyCSR(api.HostCSR(r1 - r0, N, IRP[r0:r1 + 1] - IRP[r0], JA[b0:b1], AS[b0:b1]))
+        api.build_stripes(blk, deterministic=True)
+        parts.append(_run(api, "hipSpMVStripesCSR", blk, x, r1 - r0))
+        blk.free()
+    assert np.array_equal(np.concatenate(parts), ys[0])
 
 
 def test_tiles_build_options(api, oracle):

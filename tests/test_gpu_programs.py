@@ -75,6 +75,27 @@ def test_harness_all_implementations_pass(name):
     assert "AVG_TIMES_ITERATION:25" in out and "MAX_ROW_NZ" in out and "omp sched gather:" in out
 
 
+def test_harness_reports_the_kernel_behind_the_reference_names(tmp_path):
+    """On a matrix large enough for the selection to measure (>= 2^18 entries) the harness shows which kernel the
+    reference's name SpmvCUDA_CSRFuncs[SpmvCUDA_CSRFuncs_WarpPerRowIdx] (src/include/SpMV.h:130-134) resolved to -- the
+    same one hipSpMVAutoCSR picks -- and every implementation still passes the gate."""
+    rng = np.random.default_rng(41)
+    M = N = 30_000
+    IRP, JA, AS = random_csr(rng, M, N, np.full(M, 10))
+    mtx = tmp_path / "u30k.mtx"
+    with open(mtx, "w") as f:
+        f.write("%%MatrixMarket matrix coordinate real general\n")
+        f.write(f"{M} {N} {JA.size}\n")
+        rows = np.repeat(np.arange(M), 10)
+        np.savetxt(f, np.column_stack([rows + 1, JA.astype(np.int64) + 1, AS]), fmt="%d %d %.17g")
+    r = subprocess.run([HARNESS, str(mtx), "RNDVECT", "CUDA_ONLY"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    picks = [l for l in r.stdout.splitlines() if l.startswith("#auto CSR")]
+    assert len(picks) == 2 and picks[0].startswith("#auto CSR 1\tpick:hipSpMV") and picks[1].startswith("#auto CSR 5\tpick:hipSpMV")
+    assert picks[0].split("\t")[1] == picks[1].split("\t")[1]
+    assert "msStripes:0.0" not in picks[1]                    # the candidates were really measured
+
+
 def test_harness_thread_sweep():
     """DECREASE_THREAD_NUM (test/SpMV_test.cu:73-78): every OpenMP implementation measured with 3, 2 and 1 threads"""
     r = subprocess.run([HARNESS, os.path.join(GOLD, "rand300.mtx"), os.path.join(GOLD, "x_rand300.bin")],
@@ -86,35 +107,65 @@ def test_harness_thread_sweep():
 
 
 def test_sharded_single_process_path(oracle):
+    """spmvHipShardCSR / spmvHipShardCSRGroups / spmvHipSpMVSharded on one device: 1, 2 and 3 row groups (the gather of
+    group g on its own stream while group g+1 is computed), with and without RCCL (a 1-rank communicator), mode 0 (the
+    serial-order kernel: y bit-identical to the oracle) and mode 1 (the kernel hipSpMVWarpPerRowCSR runs: every block is
+    large enough -- >= 2^18 entries -- for the per-block selection among the reduction-order kernels to really measure)."""
     from spmv_openmp_cuda_amd import api
+    from conftest import tight_error
     api.spmvHipInit(0)
     rng = np.random.default_rng(5)
-    M, N = 5000, 4000
-    lens = rng.integers(0, 50, size=M)
+    M, N = 90_000, 70_000
+    lens = rng.integers(0, 24, size=M)
     lens[77] = 3500
+    lens[::11] = 0
     IRP, JA, AS = random_csr(rng, M, N, lens)
+    assert JA.size >= 3 * (1 << 18)
     x = np.sin(rng.uniform(0, 7, N)) * 3e-5
     y_ref = oracle.csr_serial(IRP, JA, AS, x)
     host = api.HostCSR(M, N, IRP, JA, AS)
-    api.lib.spmvHipShardCSR.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]
-    api.lib.spmvHipSpMVSharded.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double)]
-    api.lib.spmvHipShardFree.argtypes = [C.c_void_p]
-    for force in ("0", "1"):
-        os.environ["SPMV_SHARD_FORCE_RCCL"] = force
-        h = C.c_void_p()
-        assert api.lib.spmvHipShardCSR(C.byref(host.struct), 1, C.byref(h)) == 0
-        for mode, exact in ((0, True), (1, False)):
-            y = np.full(M, np.nan)
-            ks, gs = C.c_double(), C.c_double()
-            assert api.lib.spmvHipSpMVSharded(h, x.ctypes.data_as(C.c_void_p), mode, y.ctypes.data_as(C.c_void_p),
-                                              C.byref(ks), C.byref(gs)) == 0
-            assert not np.isnan(y).any() and np.max(np.abs(y - y_ref)) <= 7e-4
-            if exact:
-                assert np.array_equal(y, y_ref)
-            assert ks.value > 0
-        api.lib.spmvHipShardFree(h)
-    os.environ.pop("SPMV_SHARD_FORCE_RCCL")
-    # asking for more devices than exist fails loudly
+    try:
+        for force, groups in (("0", 0), ("1", 1), ("1", 2), ("0", 3), ("1", 3)):
+            os.environ["SPMV_SHARD_FORCE_RCCL"] = force
+            h = C.c_void_p()
+            if groups:
+                assert api.lib.spmvHipShardCSRGroups(C.byref(host.struct), 1, groups, C.byref(h)) == 0
+            else:
+                assert api.lib.spmvHipShardCSR(C.byref(host.struct), 1, C.byref(h)) == 0
+            for mode, exact in ((0, True), (1, False), (1, False), (0, True)):
+                y = np.full(M, np.nan)
+                ks, gs = C.c_double(), C.c_double()
+                assert api.lib.spmvHipSpMVSharded(h, x.ctypes.data_as(C.c_void_p), mode, y.ctypes.data_as(C.c_void_p),
+                                                  C.byref(ks), C.byref(gs)) == 0, (force, groups, mode)
+                assert not np.isnan(y).any() and np.max(np.abs(y - y_ref)) <= 7e-4, (force, groups, mode)
+                if exact:
+                    assert np.array_equal(y, y_ref)
+                else:
+                    assert tight_error(IRP, JA, AS, x, y_ref, y) <= 1e-13
+                assert ks.value > 0 and gs.value >= 0
+            api.lib.spmvHipShardFree(h)
+    finally:
+        os.environ.pop("SPMV_SHARD_FORCE_RCCL", None)
+    # asking for more devices than exist, or an absurd group count, fails loudly
     h = C.c_void_p()
     assert api.lib.spmvHipShardCSR(C.byref(host.struct), 64, C.byref(h)) != 0
+    assert api.lib.spmvHipShardCSRGroups(C.byref(host.struct), 1, 1000, C.byref(h)) != 0
     api.spmvHipFinalize()
+
+
+def test_bench_spawns_its_own_ranks():
+    """`python bench.py --gpus 2` with NO external launcher in the environment: bench.py must start its ranks itself
+    (fresh processes through torch.distributed.run), relay rank 0's ONE JSON line on stdout and its exit code.  Here as a
+    shared-GPU rehearsal (both ranks on device 0, gloo as control plane) on a 5 % workload."""
+    import json
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT",
+                                                              "TORCHELASTIC_RUN_ID", "GROUP_RANK", "LOCAL_WORLD_SIZE")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--rehearse-shared-gpu", "--scale", "0.05",
+                        "--steps", "3", "--warmup", "1", "--exchange-budget", "20"], capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, r.stdout[-2000:]
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["metric"] == "spmv_gflops" and line["value"] > 0
+    assert line["parity"]["ok"] is True

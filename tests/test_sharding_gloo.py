@@ -86,13 +86,14 @@ def test_bin_ranges_cover_and_align():
 class _CpuExchange:
     """a candidate of search_exchange on CPU: the oracle computes this rank's rows, gloo gathers them"""
 
-    def __init__(self, key, plan, rank, irp, w, x, oracle, sharding, corrupt=False):
+    def __init__(self, key, plan, rank, irp, w, x, oracle, sharding, corrupt=False, fail_from_step=0):
         import torch as T
         self.key, self.plan, self.rank, self.irp, self.w, self.x, self.oracle, self.sharding = key, plan, rank, irp, w, x, oracle, sharding
         self.bufs = sharding.GatherBuffers(plan, rank, T, "cpu")
         self.y = self.bufs.y
         self.corrupt = corrupt
         self.freed = False
+        self.fail_from_step, self.steps_done = fail_from_step, 0
 
     def poison(self):
         for b in self.bufs.ypad:
@@ -102,7 +103,11 @@ class _CpuExchange:
     def step(self):
         from spmv_openmp_cuda_amd import synth
 
+        self.steps_done += 1
+
         def compute_group(g, slot):
+            if self.fail_from_step and self.steps_done >= self.fail_from_step:
+                raise RuntimeError("launcher failed")             # e.g. a kernel launch returning EXIT_FAILURE on this rank
             b0, b1 = self.plan.block(self.rank, g)
             ja, as_ = self.oracle.synth_fill(self.w.N, b0, self.irp[b0:b1 + 1], synth.SEED_STRUCT + self.w.cfg, synth.SEED_VAL + self.w.cfg, 0)
             il = (self.irp[b0:b1 + 1] - self.irp[b0]).astype(np.uint32)
@@ -131,7 +136,8 @@ def _search_worker(rank, world, port, out_dir):
     ja_all, as_all = oracle.synth_fill(w.N, 0, irp, synth.SEED_STRUCT + w.cfg, synth.SEED_VAL + w.cfg, 0)
     y_ref = oracle.csr_serial_dev(irp.astype(np.uint32), ja_all, as_all, x)
     K = sharding.ExchangeKey
-    keys = [K("rccl", groups=1), K("rccl", groups=3), K("push", 1), K("fused"), K("rccl", groups=2), K("rccl", groups=4)]
+    keys = [K("rccl", groups=1), K("rccl", groups=3), K("push", 1), K("fused"), K("rccl", groups=2), K("rccl", groups=4),
+            K("rccl", groups=5)]
     made = []
 
     def make(key):
@@ -141,8 +147,10 @@ def _search_worker(rank, world, port, out_dir):
             cand = _CpuExchange(key, sharding.make_plan(irp, world, 1), rank, irp, w, x, oracle, sharding)
         else:
             # groups = 2: a wrong y on rank 0 only
+            # groups = 5: the SECOND step (the first timed one) raises on the last rank only, before its first kernel
             cand = _CpuExchange(key, sharding.make_plan(irp, world, key.groups), rank, irp, w, x, oracle, sharding,
-                                corrupt=(key.groups == 2 and rank == 0))
+                                corrupt=(key.groups == 2 and rank == 0),
+                                fail_from_step=2 if key.groups == 5 and rank == world - 1 else 0)
         made.append(cand)
         return cand
 
@@ -157,7 +165,8 @@ def _search_worker(rank, world, port, out_dir):
                                          on_resolved=lambda i, bk: resolved.append((i, bk.name if bk else None)))
     ok = best is not None and not best.freed and rep["chosen"] in ("rccl-g1", "rccl-g3", "rccl-g4")
     ok = ok and set(rep["exchange_step_ms"]) == {"rccl-g1", "rccl-g3", "rccl-g4"}
-    ok = ok and rep["exchange_rejected"] == {"push-p1": "set-up failed on some rank", "rccl-g2": "y incomplete or different on some rank"}
+    ok = ok and rep["exchange_rejected"] == {"push-p1": "set-up failed on some rank", "rccl-g2": "y incomplete or different on some rank",
+                                             "rccl-g5": "a timed step failed on some rank"}
     ok = ok and list(rep["exchange_skipped"]) == ["fused"]             # no push candidate was validated
     ok = ok and [i for i, _ in resolved] == list(range(len(keys)))
     ok = ok and all(c.freed for c in made if c is not best)
@@ -175,7 +184,8 @@ def _search_worker(rank, world, port, out_dir):
 def test_exchange_search_takes_the_same_branch_on_every_rank(tmp_path, world):
     """bench.py's start-up search over exchange candidates (sharding.search_exchange) on gloo, with a plan whose row
     count no (world x groups) divides: a candidate that cannot be built on ONE rank and one whose y is wrong on ONE rank
-    are dropped on ALL ranks, kernel-issued stores are skipped while no push candidate has delivered, losers are freed,
+    are dropped on ALL ranks -- as is one whose step raises on ONE rank during the timed phase (the step keeps its
+    collectives matched, nobody hangs) --, kernel-issued stores are skipped while no push candidate has delivered, losers are freed,
     and an exhausted budget ends the search on every rank at the same candidate."""
     port = _free_port()
     mp.spawn(_search_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
