@@ -57,6 +57,12 @@ void          freeMatrixMarket(MatrixMarket* mm);
  * files are mirrored, pattern files get value 1.0; *NZ is updated and
  * rowLens[] (zeroed by the caller, M entries) counts entries per row */
 entry*        MMtoCOO(ulong* NZ, FILE* fp, MM_typecode mcode, ulong* rowLens);
+/* The same from memory, by all host cores (csrc/host/mmfast.c): buf[0..len) is everything behind the size line,
+ * buf[len] == 0.  *status: 0, MMFAST_ERROR (message printed) or MMFAST_FALLBACK (the entries are not laid out one per
+ * line, or something the tokeniser does not want to judge: parse the stream with MMtoCOO instead). */
+#define MMFAST_ERROR    1
+#define MMFAST_FALLBACK 2
+entry*        MMtoCOOFromBuffer(ulong* NZ, const char* buf, size_t len, MM_typecode mcode, ulong M, ulong N, ulong* rowLens, int* status);
 /* COO -> CSR / ELL.  Entries of one row must arrive in ascending column order
  * (any interleaving of rows); otherwise EXIT_FAILURE. */
 int           COOtoCSR(entry* entries, spmat* mat, ulong* rowLens);

@@ -307,8 +307,13 @@ int spmvHipTilesShape(spmat* dMat, unsigned* nBins, unsigned* rowsPerBin);
  *               gives the first row of any bin (bin == nBins: the row count).
  *   ntStore     1 / 0: phase 1 stores the products non-temporally / with the default policy; -1: by size
  *               (products that fit the 256 MiB Infinity Cache are kept there).
- *   chunk       entries per phase-1 work item, 0 or 4096..2^24. */
-typedef struct { unsigned rowsPerBin; int taper; int ntStore; unsigned chunk; } spmvTilesOpts;
+ *   chunk       entries per phase-1 work item, 0 or 4096..2^24.
+ *   deterministic  1: every row is added by ONE wavefront in ascending column order (a bin is four sub-bins, each walked by
+ *               one wavefront), so y is the same bits in every run and on any number of row shards, and -- products being
+ *               rounded before they are added -- the bits of the serial oracle when the columns of every row ascend.
+ *               Costs time: four wavefronts per CU instead of sixteen, tiles a quarter as long.  No
+ *               tapered bins in this form. */
+typedef struct { unsigned rowsPerBin; int taper; int ntStore; unsigned chunk; int deterministic; } spmvTilesOpts;
 int spmvHipBuildTilesOpt(spmat* dMat, const spmvTilesOpts* opts);
 typedef struct {
     unsigned nBins, rowsPerBin, nSlices;
@@ -316,8 +321,9 @@ typedef struct {
     unsigned chunk;
     double   buildMs;          /* wall time of the one-time build, allocations included */
     size_t   bytes;            /* device memory of the format (the shared product workspace not included) */
-    double   allocMs;          /* the part of buildMs the host spent in hipMalloc: format, product workspace and 36 B per
-                                * entry of temporaries (c5: ~90 GB mapped -- seconds; the build kernels themselves ~0.1 s) */
+    double   allocMs;          /* the part of buildMs the host spent in hipMalloc: format, product workspace, temporaries */
+    size_t   tempBytes;        /* peak of the temporaries of the build (12 B per entry + the tile tables; freed when it returns) */
+    int      deterministic;
 } spmvTilesInfo;
 int spmvHipTilesInfo(spmat* dMat, spmvTilesInfo* info);   /* zeros when the format has not been built */
 int spmvHipTilesBinRow(spmat* dMat, unsigned bin, ulong* firstRow);

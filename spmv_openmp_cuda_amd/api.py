@@ -97,15 +97,16 @@ _sigs = {
 
 class spmvTilesOpts(C.Structure):
     """include/spmvHip.h `spmvTilesOpts` (0 / 0 / -1 / 0 = automatic)."""
-    _fields_ = [("rowsPerBin", C.c_uint), ("taper", _i), ("ntStore", _i), ("chunk", C.c_uint)]
+    _fields_ = [("rowsPerBin", C.c_uint), ("taper", _i), ("ntStore", _i), ("chunk", C.c_uint), ("deterministic", _i)]
 
-    def __init__(self, rowsPerBin=0, taper=0, ntStore=-1, chunk=0):
-        super().__init__(rowsPerBin, taper, ntStore, chunk)
+    def __init__(self, rowsPerBin=0, taper=0, ntStore=-1, chunk=0, deterministic=0):
+        super().__init__(rowsPerBin, taper, ntStore, chunk, deterministic)
 
 
 class spmvTilesInfo(C.Structure):
     _fields_ = [("nBins", C.c_uint), ("rowsPerBin", C.c_uint), ("nSlices", C.c_uint), ("taper", _i), ("ntStore", _i),
-                ("chunk", C.c_uint), ("buildMs", C.c_double), ("bytes", _sz), ("allocMs", C.c_double)]
+                ("chunk", C.c_uint), ("buildMs", C.c_double), ("bytes", _sz), ("allocMs", C.c_double), ("tempBytes", _sz),
+                ("deterministic", _i)]
 
 
 class spmvStripesOpts(C.Structure):
@@ -377,9 +378,9 @@ def spmv(launcher: str, dmat: DeviceMatrix, dx: DeviceVector, dy: DeviceVector, 
     _check(fn(C.byref(dmat.handle), dx.ptr, cfg if cfg is not None else CONFIG(), dy.ptr), launcher)
 
 
-def build_tiles(dmat: DeviceMatrix, rowsPerBin=0, taper=False, ntStore=-1, chunk=0):
+def build_tiles(dmat: DeviceMatrix, rowsPerBin=0, taper=False, ntStore=-1, chunk=0, deterministic=False):
     """spmvHipBuildTilesOpt: (re)build the two-phase format of this handle with explicit options."""
-    o = spmvTilesOpts(int(rowsPerBin), 1 if taper else 0, int(ntStore), int(chunk))
+    o = spmvTilesOpts(int(rowsPerBin), 1 if taper else 0, int(ntStore), int(chunk), 1 if deterministic else 0)
     _check(lib.spmvHipBuildTilesOpt(C.byref(dmat.handle), C.byref(o)), "spmvHipBuildTilesOpt")
 
 

@@ -481,16 +481,21 @@ int buildStripes(DevMat* d, const spmvStripesOpts* opts) {
         hipLaunchKernelGGL((sb_keys_kernel<uint64_t>), grid2d((M + 3) / 4, 256), dim3(256), 0, nullptr, M, static_cast<const uint64_t*>(d->IRP), d->JA,
                            f->binRow, B, f->subs, colBits, keys.as<uint64_t>(), idx.as<uint32_t>(), rowOf.as<uint32_t>());
     if (hipGetLastError() != hipSuccess) return fail("key kernel");
+    // (rocPRIM's double-buffer interface: the sort ping-pongs between the two pairs of buffers given here instead of
+    // allocating a third full-size pair inside its temporary storage)
+    rocprim::double_buffer<uint64_t> dKeys(keys.as<uint64_t>(), keysOut.as<uint64_t>());
+    rocprim::double_buffer<uint32_t> dIdx(idx.as<uint32_t>(), perm.as<uint32_t>());
     size_t tmpBytes = 0;
-    if (rocprim::radix_sort_pairs(nullptr, tmpBytes, keys.as<uint64_t>(), keysOut.as<uint64_t>(), idx.as<uint32_t>(), perm.as<uint32_t>(),
-                                  (size_t)nnz, 0, colBits + groupBits, (hipStream_t) nullptr) != hipSuccess || sortTmp.alloc(tmpBytes))
+    if (rocprim::radix_sort_pairs(nullptr, tmpBytes, dKeys, dIdx, (size_t)nnz, 0, colBits + groupBits, (hipStream_t) nullptr) != hipSuccess ||
+        sortTmp.alloc(tmpBytes))
         return fail("sort workspace");
-    if (rocprim::radix_sort_pairs(sortTmp.p, tmpBytes, keys.as<uint64_t>(), keysOut.as<uint64_t>(), idx.as<uint32_t>(), perm.as<uint32_t>(),
-                                  (size_t)nnz, 0, colBits + groupBits, (hipStream_t) nullptr) != hipSuccess)
+    if (rocprim::radix_sort_pairs(sortTmp.p, tmpBytes, dKeys, dIdx, (size_t)nnz, 0, colBits + groupBits, (hipStream_t) nullptr) != hipSuccess)
         return fail("sort");
+    const uint64_t* const skeys = dKeys.current();
+    const uint32_t* const sperm = dIdx.current();
 
     // where every sub-stream starts in the sorted order -> its first step (each sub-stream is padded to whole steps)
-    hipLaunchKernelGGL(sb_bounds_kernel, grid2d((nnz + 255) / 256, 256), dim3(256), 0, nullptr, nnz, colBits, keysOut.as<uint64_t>(), nGroups,
+    hipLaunchKernelGGL(sb_bounds_kernel, grid2d((nnz + 255) / 256, 256), dim3(256), 0, nullptr, nnz, colBits, skeys, nGroups,
                        dStart.as<uint64_t>());
     if (hipGetLastError() != hipSuccess) return fail("bounds kernel");
     std::vector<uint64_t> start(nGroups + 1);
@@ -508,7 +513,7 @@ int buildStripes(DevMat* d, const spmvStripesOpts* opts) {
 
     bool wide = o.wide > 0;
     for (int attempt = 0; attempt < 2; ++attempt) {
-        if (fillFormat(f, wide, nnz, colBits, keysOut.as<uint64_t>(), perm.as<uint32_t>(), rowOf.as<uint32_t>(), d->AS,
+        if (fillFormat(f, wide, nnz, colBits, skeys, sperm, rowOf.as<uint32_t>(), d->AS,
                        dStart.as<uint64_t>(), dOverflow.as<uint32_t>()))
             return fail("scatter");
         uint32_t ovf = 0;

@@ -48,12 +48,15 @@
 
 namespace spmvhip {
 
-constexpr uint32_t PB_C       = 16384;              // columns per slice: 16 Ki = 128 KiB of x in LDS (19 Ki = 152 KiB measured no faster: c3 1.075 vs 1.050 ms, c5 equal)
+constexpr uint32_t PB_CBITS   = 14;
+constexpr uint32_t PB_C       = 1u << PB_CBITS;     // columns per slice: 16 Ki = 128 KiB of x in LDS (19 Ki = 152 KiB measured no faster: c3 1.075 vs 1.050 ms, c5 equal)
 static_assert(PB_C % 1024 == 0 && PB_C * 8 <= 160 * 1024 && PB_C <= 65536, "slice width");
 constexpr uint32_t PB_R_MAX   = 20000;             // rows per bin: <= 156 KiB of y in LDS (160 KiB per CU on gfx950)
 constexpr uint32_t PB_CUS_DEFAULT = 256;           // compute units when the device does not say (phase 2 keeps one workgroup per CU)
 constexpr uint32_t PB_CHUNK   = 1u << 17;           // entries of one slice handled by one phase-1 workgroup
 constexpr int      PB_THREADS = 1024;
+constexpr uint32_t PD_WAVES   = 4;                 // deterministic form: wavefronts of a phase-2 workgroup = sub-bins of a bin
+constexpr int      PD_THREADS = PD_WAVES * 64;
 constexpr size_t   PB_RESIDENT_BYTES = 288ull << 20; // products up to this size stay in the 256 MiB Infinity Cache between the phases (c2, 244 MiB: 0.156 ms plain vs 0.176 ms nt stores)
 
 // Rows -> bins.  Up to three zones of equal-height bins: n1 bins of a rows, n2 bins of b rows, the rest c rows
@@ -79,9 +82,12 @@ struct TileFormat {
     uint32_t S = 0, B = 0, R = 0;                   // slices, bins, rows of the highest bin
     BinMap    bins;
     uint64_t nnz = 0;
+    void*     slab = nullptr;                       // ONE allocation behind val / lcol / lrow (it doubles as sort buffer while the format is built)
     double*   val = nullptr;                        // slice-major values
     uint16_t* lcol = nullptr;                       // slice-major: column - slice*PB_C
     uint16_t* lrow = nullptr;                       // BIN-major: row - bin*R
+    bool      det = false;                          // deterministic form: `bins` / B / binPos / waveTile describe SUB-bins (PD_WAVES per bin of the API)
+    size_t    tempBytes = 0;                        // peak of the temporaries of the build
     uint2*    tl = nullptr;                         // non-empty tiles in bin-major order: {first bin-major position,
                                                     // slice-major start - bin-major start (mod 2^32)}; sentinels follow
     uint32_t  nList = 0;
@@ -95,7 +101,11 @@ struct TileFormat {
     uint32_t  epoch = 0;
     uint32_t  cus = PB_CUS_DEFAULT;                 // CUs of the device the format was built on
     size_t    bytes = 0;
-    spmvTilesOpts opts{0, 0, -1, 0};                // what the format was built with (0 / -1 = automatic)
+    spmvTilesOpts opts{0, 0, -1, 0, 0};             // what the format was built with (0 / -1 = automatic)
+    // what the API calls a bin (spmvHipTilesShape, hipSpMVTilesReduce): the deterministic form groups PD_WAVES sub-bins
+    uint32_t apiBins() const { return det ? (B + PD_WAVES - 1) / PD_WAVES : B; }
+    uint32_t apiRows() const { return det ? PD_WAVES * bins.c : R; }
+    BinMap   apiMap() const { if (!det) return bins; BinMap m; m.c = PD_WAVES * bins.c; return m; }
     uint32_t  chunk = 0;                            // phase-1 work item size in entries actually used
     double    buildMs = 0;                          // wall time of the one-time build (events on the null stream around it)
     double    allocMs = 0;                          // ... of which the host spent in hipMalloc (format, product workspace, 36 B/entry of temporaries)
@@ -112,35 +122,49 @@ __device__ __forceinline__ uint64_t lin_block() { return (uint64_t)blockIdx.y * 
 // What travels through the sort with every entry: the sort moves {value, local column, row} itself, so that nothing
 // has to be fetched through a permutation afterwards (a first version sorted indices and then gathered AS, JA and the
 // row of every entry through them: 1.6 G x 3 isolated 128-B line fetches = 165 of the 217 ms of the c5 build).
-struct PbPay { double val; uint32_t row; uint32_t lcol; };
-static_assert(sizeof(PbPay) == 16, "payload layout");
+// ... 12 bytes: the value as two words (the struct then needs 4-byte alignment only) and the row; the local column rides in the
+// low bits of the 32-bit sort key (slice << 14 | local column, sorted on the slice bits only: stable, so the (row, column)
+// order of the CSR survives inside every slice).
+struct PbPay { uint32_t vlo, vhi, row; };
+static_assert(sizeof(PbPay) == 12 && alignof(PbPay) == 4, "payload layout");
+__host__ __device__ __forceinline__ PbPay pb_pack(double v, uint32_t row) {
+    uint64_t b;
+    memcpy(&b, &v, 8);
+    return PbPay{(uint32_t)b, (uint32_t)(b >> 32), row};
+}
+__host__ __device__ __forceinline__ double pb_value(const PbPay& e) {
+    const uint64_t b = ((uint64_t)e.vhi << 32) | e.vlo;
+    double v;
+    memcpy(&v, &b, 8);
+    return v;
+}
 
 // one wavefront per row: slice id (the sort key) and payload of every entry, in CSR order
 template <typename I>
 __global__ __launch_bounds__(256) void pb_payload_kernel(uint64_t M, const I* __restrict__ IRP, const uint32_t* __restrict__ JA,
-                                                         const double* __restrict__ AS, uint16_t* __restrict__ keys,
+                                                         const double* __restrict__ AS, uint32_t* __restrict__ keys,
                                                          PbPay* __restrict__ pay) {
     const uint64_t r = lin_block() * 4 + threadIdx.x / 64;
     if (r >= M) return;
     const uint64_t b = IRP[r], e = IRP[r + 1];
     for (uint64_t j = b + threadIdx.x % 64; j < e; j += 64) {
         const uint32_t c = JA[j];
-        keys[j] = (uint16_t)(c / PB_C);
-        pay[j] = PbPay{AS[j], (uint32_t)r, c % PB_C};
+        keys[j] = c;                                 // = slice << PB_CBITS | local column
+        pay[j] = pb_pack(AS[j], (uint32_t)r);
     }
 }
 
 // mark where each tile starts in the sorted (slice-major) order.  tile id t = slice*B + bin is non-decreasing
 // along that order, so the first entry of a tile also fills the start of every empty tile before it.
 __global__ __launch_bounds__(256) void pb_bounds_kernel(
-    uint64_t nnz, const PbPay* __restrict__ spay, const uint16_t* __restrict__ skeys,
+    uint64_t nnz, const PbPay* __restrict__ spay, const uint32_t* __restrict__ skeys,
     uint32_t B, BinMap bm, uint64_t nTiles, uint32_t* __restrict__ tileStart) {
     const uint64_t p = lin_block() * 256 + threadIdx.x;
     if (p >= nnz) return;
-    const uint64_t t = (uint64_t)skeys[p] * B + bm.binOf(spay[p].row);
+    const uint64_t t = (uint64_t)(skeys[p] >> PB_CBITS) * B + bm.binOf(spay[p].row);
     uint64_t tPrev;                                  // tile of the previous entry, or "-1"
     if (p == 0) tPrev = ~0ull;
-    else tPrev = (uint64_t)skeys[p - 1] * B + bm.binOf(spay[p - 1].row);
+    else tPrev = (uint64_t)(skeys[p - 1] >> PB_CBITS) * B + bm.binOf(spay[p - 1].row);
     if (t != tPrev)
         for (uint64_t u = tPrev + 1; u <= t; ++u) tileStart[u] = (uint32_t)p;      // tPrev+1 wraps to 0 for p == 0
     if (p == nnz - 1)
@@ -179,15 +203,16 @@ __global__ __launch_bounds__(256) void pb_list_kernel(uint32_t S, uint32_t B, ui
 // the sorted payload is already slice-major: split it into the value and local-column streams, and place the local
 // rows in bin-major order
 __global__ __launch_bounds__(256) void pb_place_kernel(
-    uint64_t nnz, const PbPay* __restrict__ spay, const uint16_t* __restrict__ skeys,
+    uint64_t nnz, const PbPay* __restrict__ spay, const uint32_t* __restrict__ skeys,
     uint32_t S, uint32_t B, BinMap bm, const uint32_t* __restrict__ tileStart, const uint32_t* __restrict__ bmStart,
     double* __restrict__ val, uint16_t* __restrict__ lcol, uint16_t* __restrict__ lrow) {
     const uint64_t p = lin_block() * 256 + threadIdx.x;
     if (p >= nnz) return;
     const PbPay e = spay[p];
-    const uint32_t bin = bm.binOf(e.row), slice = skeys[p];
-    val[p] = e.val;
-    lcol[p] = (uint16_t)e.lcol;
+    const uint32_t key = skeys[p];
+    const uint32_t bin = bm.binOf(e.row), slice = key >> PB_CBITS;
+    val[p] = pb_value(e);
+    lcol[p] = (uint16_t)(key & (PB_C - 1));
     const uint32_t within = (uint32_t)p - tileStart[(uint64_t)slice * B + bin];
     lrow[bmStart[(uint64_t)bin * S + slice] + within] = (uint16_t)(e.row - bm.row0(bin));
 }
@@ -372,6 +397,36 @@ __device__ __forceinline__ void p2_add_runs(double* yb, uint16_t rv, double pv, 
     if (!follows && rv != P2_NONE) atomicAdd(&yb[rv], v);
 }
 
+// the finished bin: y, then -- by MODE -- the other ranks' copies of y or the ready flag of the push kernel
+template <int MODE, int THREADS>
+__device__ __forceinline__ void p2_finish(const double* yb, uint32_t R, uint64_t r0, uint64_t M, double* __restrict__ y,
+                                          const TileDst& extra, const TileSignal& sig, uint32_t bin) {
+    for (uint32_t k = threadIdx.x; k < R; k += THREADS)
+        if (r0 + k < M) y[r0 + k] = yb[k];
+    if (MODE == 1) {
+        // destination-major (long contiguous runs per link); workgroups start at different destinations so that
+        // all links carry traffic all the time
+        for (uint32_t i = 0; i < extra.n; ++i) {
+            double* __restrict__ dst = extra.p[(i + bin) % extra.n];
+            for (uint32_t k = threadIdx.x; k < R; k += THREADS)
+                if (r0 + k < M) dst[r0 + k] = yb[k];
+        }
+    }
+    if (MODE == 2) {
+        // hand the finished bin to the push kernel (another CU, maybe another XCD): every storing wave waits for its
+        // stores, the workgroup meets, ONE lane writes the XCD's L2 back (agent release) and only then sets the flag
+        // (MI355X_MICROARCH.md "inter-workgroup visibility", producer form; the explicit wait after the fence is the
+        // documented guard against the compiler dropping it)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __hip_atomic_store(sig.ready + bin, sig.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
 // MULTI: the finished bin of y is also stored to `extra.n` further destinations -- the copies of y that the other
 // ranks of a multi-GPU run hold, mapped into this process (peer windows over xGMI, peer.hip): the all-gather of y
 // is fused into the producing kernel as point-to-point stores, one 512-B run per wavefront instruction.
@@ -429,31 +484,57 @@ __global__ __launch_bounds__(PB_THREADS) void pb_reduce_kernel(
         }
     }
     __syncthreads();
-    const uint64_t r0 = bm.row0((uint32_t)bin);
-    for (uint32_t k = threadIdx.x; k < R; k += PB_THREADS)
-        if (r0 + k < M) y[r0 + k] = yb[k];
-    if (MODE == 1) {
-        // destination-major (long contiguous runs per link); workgroups start at different destinations so that
-        // all links carry traffic all the time
-        for (uint32_t i = 0; i < extra.n; ++i) {
-            double* __restrict__ dst = extra.p[(i + (uint32_t)bin) % extra.n];
-            for (uint32_t k = threadIdx.x; k < R; k += PB_THREADS)
-                if (r0 + k < M) dst[r0 + k] = yb[k];
+    p2_finish<MODE, PB_THREADS>(yb, R, bm.row0((uint32_t)bin), M, y, extra, sig, (uint32_t)bin);
+}
+
+// Deterministic form of phase 2.  A bin of the API is PD_WAVES consecutive SUB-bins; the format's tables (bins, binPos,
+// tile list, local rows) are built on the sub-bins, and wavefront w of the bin's workgroup walks sub-bin w from its first
+// entry to its last in bin-major order -- slice by slice, a tile sorted by (row, column) -- with plain ds_add_f64.  A row
+// therefore receives its products from ONE wavefront in ascending column order (lanes of one instruction that meet in a row
+// are served in lane order), which is the order of the serial oracle, whatever the scheduler does and however the rows were
+// cut into bins or shards.  Cost: 4 wavefronts per CU instead of 16 to keep the two streams in flight, and tiles a quarter as
+// long (c5: 20 instead of 80 entries).
+template <int MODE>
+__global__ __launch_bounds__(PD_THREADS) void pb_reduce_det_kernel(
+    BinMap bm, uint32_t nSub, uint32_t binBegin, uint32_t binEnd, uint64_t M, const uint32_t* __restrict__ binPos,
+    const uint32_t* __restrict__ subTile, const uint2* __restrict__ tl, const double* __restrict__ prod,
+    const uint16_t* __restrict__ lrow, double* __restrict__ y, TileDst extra, TileSignal sig) {
+    extern __shared__ double yb[];                  // PD_WAVES * (rows of a sub-bin) doubles
+    const uint64_t bin = binBegin + lin_block();
+    if (bin >= binEnd) return;
+    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x / 64)), lane = threadIdx.x % 64;
+    const uint32_t sb = (uint32_t)bin * PD_WAVES + wave;
+    const uint32_t Rs = bm.c;                        // uniform sub-bin height (no tapered zones in this form)
+    double* yw = yb + wave * Rs;
+    uint32_t wb = 0, we = 0;
+    if (sb < nSub) { wb = binPos[sb]; we = binPos[sb + 1]; }
+    const bool busy = we > wb;                       // uniform per wavefront
+    P2Cursor c;
+    P2Regs a, b;
+    if (busy) {
+        c.k = subTile[sb];
+        c.delta = tl[c.k].y;
+        c.n1 = tl[c.k + 1];
+        c.n2 = tl[c.k + 2];
+        p2_fetch(a, c, wb, we, lane, tl, prod, lrow);
+    }
+    const uint32_t R = PD_WAVES * Rs;
+    for (uint32_t k = threadIdx.x; k < R; k += PD_THREADS) yb[k] = 0.0;
+    __syncthreads();
+    if (busy) {
+        for (uint32_t v = wb; v < we; v += 2 * P2_DEPTH * 64) {
+            p2_fetch(b, c, v + P2_DEPTH * 64, we, lane, tl, prod, lrow);
+#pragma unroll
+            for (int u = 0; u < P2_DEPTH; ++u)
+                if (a.rv[u] != P2_NONE) atomicAdd(&yw[a.rv[u]], a.pv[u]);
+            p2_fetch(a, c, v + 2 * P2_DEPTH * 64, we, lane, tl, prod, lrow);
+#pragma unroll
+            for (int u = 0; u < P2_DEPTH; ++u)
+                if (b.rv[u] != P2_NONE) atomicAdd(&yw[b.rv[u]], b.pv[u]);
         }
     }
-    if (MODE == 2) {
-        // hand the finished bin to the push kernel (another CU, maybe another XCD): every storing wave waits for its
-        // stores, the workgroup meets, ONE lane writes the XCD's L2 back (agent release) and only then sets the flag
-        // (MI355X_MICROARCH.md "inter-workgroup visibility", producer form; the explicit wait after the fence is the
-        // documented guard against the compiler dropping it)
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __hip_atomic_store(sig.ready + bin, sig.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-    }
+    __syncthreads();
+    p2_finish<MODE, PD_THREADS>(yb, R, bm.row0((uint32_t)bin * PD_WAVES), M, y, extra, sig, (uint32_t)bin);
 }
 
 // The push kernel: runs BESIDE phase 2 (own stream, a few wavefronts per CU, no LDS -- phase 2 leaves wave slots free)
@@ -638,12 +719,13 @@ void freeTilesWorkspace() {
 
 uint64_t tilesBinRow(const DevMat* d, uint32_t bin) {
     if (!d->tiles) return 0;
-    return bin >= d->tiles->B ? d->M : std::min<uint64_t>(d->M, d->tiles->bins.row0(bin));
+    const TileFormat* t = d->tiles;
+    return bin >= t->apiBins() ? d->M : std::min<uint64_t>(d->M, t->apiMap().row0(bin));
 }
 
 void freeTiles(TileFormat* t) {
     if (!t) return;
-    (void)hipFree(t->val); (void)hipFree(t->lcol); (void)hipFree(t->lrow); (void)hipFree(t->tl);
+    (void)hipFree(t->slab); (void)hipFree(t->tl);
     (void)hipFree(t->binPos); (void)hipFree(t->waveTile); (void)hipFree(t->work); (void)hipFree(t->ready);
     delete t;
 }
@@ -652,7 +734,8 @@ void freeTiles(TileFormat* t) {
 int buildTiles(DevMat* d, const spmvTilesOpts* opts) {
     if (d->tiles && !opts) return EXIT_SUCCESS;
     if (d->kind != Kind::CSR) return EXIT_FAILURE;
-    const spmvTilesOpts o = opts ? *opts : spmvTilesOpts{0, 0, -1, 0};
+    const spmvTilesOpts o = opts ? *opts : spmvTilesOpts{0, 0, -1, 0, 0};
+    if (o.deterministic && o.taper) { fprintf(stderr, "libspmvhip: tiles: the deterministic form has no tapered bins\n"); return EXIT_FAILURE; }
     if (o.rowsPerBin != 0 && (o.rowsPerBin < 64 || o.rowsPerBin > PB_R_MAX)) {
         fprintf(stderr, "libspmvhip: tiles: rowsPerBin = %u is not 0 (automatic) or 64..%u\n", o.rowsPerBin, PB_R_MAX);
         return EXIT_FAILURE;
@@ -714,43 +797,68 @@ int buildTiles(DevMat* d, const spmvTilesOpts* opts) {
         t->bins.z2 = t->bins.z1 + n2 * high;
         if (t->bins.z2 >= M) { t->bins.n2 = (uint32_t)((M - t->bins.z1 + high - 1) / high); t->bins.z2 = t->bins.z1 + (uint64_t)t->bins.n2 * high; }
     }
+    t->det = o.deterministic != 0;
+    if (t->det) {                                    // sub-bins: a quarter of the bin each, PD_WAVES of them share a workgroup's LDS
+        const uint32_t Rs = o.rowsPerBin ? (o.rowsPerBin + PD_WAVES - 1) / PD_WAVES
+                                         : std::min<uint32_t>(PB_R_MAX / PD_WAVES / 64 * 64, std::max<uint32_t>(64, ((R + PD_WAVES - 1) / PD_WAVES + 63) / 64 * 64));
+        t->bins = BinMap{};
+        t->bins.c = std::max<uint32_t>(1, std::min<uint32_t>(Rs, PB_R_MAX / PD_WAVES));
+    }
     t->R = t->bins.maxHeight();
     t->B = t->bins.z2 >= M ? t->bins.n1 + t->bins.n2 : t->bins.n1 + t->bins.n2 + (uint32_t)((M - t->bins.z2 + t->bins.c - 1) / t->bins.c);
     t->nnz = nnz;
     const uint64_t nTiles = (uint64_t)t->S * t->B;
     if (nTiles >= (1ull << 32) - 2) { fprintf(stderr, "libspmvhip: tiles: too many tiles\n"); return EXIT_FAILURE; }
 
-    TempBuf keys, keysOut, pay, payOut, sortTmp, tileStart;
+    // Memory.  The format's three arrays are ONE slab (val | lcol | lrow, each part 256-B aligned), and while the format is
+    // built that slab and the device's product workspace (8 B/nnz, needed anyway) serve as sort buffers: the unsorted
+    // payload lives in the slab, the two key buffers in the workspace, and the only temporary of size is the second payload
+    // buffer, 12 B/nnz (round 2 allocated 36 B/nnz of its own plus, inside rocPRIM's pointer interface, 18 more: on c5
+    // ~90 GB mapped for a 19 GB format, a second of hipMalloc).  rocPRIM's double-buffer interface sorts between the two
+    // pairs of buffers without further full-size storage.
+    TempBuf payB, sortTmp, tileStart;
     auto fail = [&](const char* what) { fprintf(stderr, "libspmvhip: tiles: %s failed\n", what); return EXIT_FAILURE; };
+    PB_TRY(hipDeviceSynchronize());                  // nothing may still use the product workspace of this device
     const auto allocT0 = std::chrono::steady_clock::now();
-    if (keys.alloc(nnz * 2) || keysOut.alloc(nnz * 2) || pay.alloc(nnz * sizeof(PbPay)) || payOut.alloc(nnz * sizeof(PbPay)) ||
-        tileStart.alloc((nTiles + 2) * 4))
-        return fail("temporary allocation (36 B per entry while the format is built)");
-    if (hipMalloc(&t->val, nnz * 8) || hipMalloc(&t->lcol, nnz * 2) || hipMalloc(&t->lrow, nnz * 2) ||
-        !prodWorkspace(nnz, true) || hipMalloc(&t->binPos, ((size_t)t->B + 1) * 4) ||
-        hipMalloc(&t->waveTile, (size_t)t->B * P2_WAVES * 4))
+    const size_t offLcol = (nnz * 8 + 255) / 256 * 256, offLrow = offLcol + (nnz * 2 + 255) / 256 * 256;
+    const size_t slabBytes = std::max<size_t>(offLrow + nnz * 2, nnz * sizeof(PbPay));
+    if (hipMalloc(&t->slab, slabBytes) || payB.alloc(nnz * sizeof(PbPay)) || tileStart.alloc((nTiles + 2) * 4))
+        return fail("format / temporary allocation (12 B per entry of temporaries while the format is built)");
+    double* const prodBuf = prodWorkspace(nnz, true);
+    if (!prodBuf || hipMalloc(&t->binPos, ((size_t)t->B + 1) * 4) || hipMalloc(&t->waveTile, (size_t)t->B * (t->det ? 1 : P2_WAVES) * 4))
         return fail("format allocation");
     t->allocMs = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - allocT0).count();
+    t->val  = static_cast<double*>(t->slab);
+    t->lcol = reinterpret_cast<uint16_t*>(static_cast<char*>(t->slab) + offLcol);
+    t->lrow = reinterpret_cast<uint16_t*>(static_cast<char*>(t->slab) + offLrow);
+    t->tempBytes = nnz * sizeof(PbPay) + (nTiles + 2) * 4;
+    uint32_t* const keysA = reinterpret_cast<uint32_t*>(prodBuf);
+    PbPay* const payA = static_cast<PbPay*>(t->slab);
 
     if (d->irpBytes == 4)
         hipLaunchKernelGGL((pb_payload_kernel<uint32_t>), grid2d((M + 3) / 4, 256), dim3(256), 0, nullptr, M, static_cast<const uint32_t*>(d->IRP), d->JA, d->AS,
-                           keys.as<uint16_t>(), pay.as<PbPay>());
+                           keysA, payA);
     else
         hipLaunchKernelGGL((pb_payload_kernel<uint64_t>), grid2d((M + 3) / 4, 256), dim3(256), 0, nullptr, M, static_cast<const uint64_t*>(d->IRP), d->JA, d->AS,
-                           keys.as<uint16_t>(), pay.as<PbPay>());
+                           keysA, payA);
     PB_TRY(hipGetLastError());
 
     unsigned bits = 1;
     while ((1u << bits) < t->S) ++bits;
+    rocprim::double_buffer<uint32_t> dKeys(keysA, keysA + nnz);
+    rocprim::double_buffer<PbPay>    dPay(payA, payB.as<PbPay>());
     size_t tmpBytes = 0;
-    PB_TRY(rocprim::radix_sort_pairs(nullptr, tmpBytes, keys.as<uint16_t>(), keysOut.as<uint16_t>(), pay.as<PbPay>(),
-                                     payOut.as<PbPay>(), (size_t)nnz, 0, bits, (hipStream_t) nullptr));
+    PB_TRY(rocprim::radix_sort_pairs(nullptr, tmpBytes, dKeys, dPay, (size_t)nnz, PB_CBITS, PB_CBITS + bits, (hipStream_t) nullptr));
     if (sortTmp.alloc(tmpBytes)) return fail("sort workspace");
-    PB_TRY(rocprim::radix_sort_pairs(sortTmp.p, tmpBytes, keys.as<uint16_t>(), keysOut.as<uint16_t>(), pay.as<PbPay>(),
-                                     payOut.as<PbPay>(), (size_t)nnz, 0, bits, (hipStream_t) nullptr));
+    t->tempBytes += tmpBytes;
+    PB_TRY(rocprim::radix_sort_pairs(sortTmp.p, tmpBytes, dKeys, dPay, (size_t)nnz, PB_CBITS, PB_CBITS + bits, (hipStream_t) nullptr));
+    const uint32_t* const skeys = dKeys.current();
+    if (dPay.current() == payA)                      // the sorted payload must not sit where val / lcol / lrow are about to be written
+        PB_TRY(hipMemcpyAsync(payB.p, payA, nnz * sizeof(PbPay), hipMemcpyDeviceToDevice, nullptr));
+    const PbPay* const spay = payB.as<PbPay>();
 
-    hipLaunchKernelGGL(pb_bounds_kernel, grid2d((nnz + 255) / 256, 256), dim3(256), 0, nullptr, nnz, payOut.as<PbPay>(),
-                       keysOut.as<uint16_t>(), t->B, t->bins, nTiles, tileStart.as<uint32_t>());
+    hipLaunchKernelGGL(pb_bounds_kernel, grid2d((nnz + 255) / 256, 256), dim3(256), 0, nullptr, nnz, spay, skeys, t->B, t->bins, nTiles,
+                       tileStart.as<uint32_t>());
     PB_TRY(hipGetLastError());
     // bin-major view: tile lengths (bin-major) -> exclusive scans give every tile's bin-major start and its index
     // in the list of non-empty tiles
@@ -759,6 +867,7 @@ int buildTiles(DevMat* d, const spmvTilesOpts* opts) {
         if (lens.alloc(nTiles * 4) || flags.alloc(nTiles * 4) || bmStart.alloc(nTiles * 4) || listIdx.alloc(nTiles * 4) ||
             binTile.alloc(((size_t)t->B + 1) * 4))
             return fail("tile-list workspace");
+        t->tempBytes += nTiles * 16;
         hipLaunchKernelGGL(pb_lens_kernel, grid2d((nTiles + 255) / 256, 256), dim3(256), 0, nullptr, t->S, t->B,
                            tileStart.as<uint32_t>(), lens.as<uint32_t>(), flags.as<uint32_t>());
         size_t scanBytes = 0;
@@ -779,20 +888,26 @@ int buildTiles(DevMat* d, const spmvTilesOpts* opts) {
         hipLaunchKernelGGL(pb_list_kernel, grid2d((nTiles + 255) / 256, 256), dim3(256), 0, nullptr, t->S, t->B, nnz,
                            tileStart.as<uint32_t>(), lens.as<uint32_t>(), bmStart.as<uint32_t>(), listIdx.as<uint32_t>(), t->nList,
                            t->tl, t->binPos, binTile.as<uint32_t>());
-        hipLaunchKernelGGL(pb_place_kernel, grid2d((nnz + 255) / 256, 256), dim3(256), 0, nullptr, nnz, payOut.as<PbPay>(),
-                           keysOut.as<uint16_t>(), t->S, t->B, t->bins, tileStart.as<uint32_t>(),
-                           bmStart.as<uint32_t>(), t->val, t->lcol, t->lrow);
-        TempBuf dupCount;
-        if (dupCount.alloc((size_t)t->B * P2_WAVES * 4)) return fail("run-count workspace");
-        PB_TRY(hipMemsetAsync(dupCount.p, 0, (size_t)t->B * P2_WAVES * 4, nullptr));
-        hipLaunchKernelGGL(pb_dupcount_kernel, grid2d((nnz + 255) / 256, 256), dim3(256), 0, nullptr, t->B, nnz, t->binPos, t->lrow,
-                           dupCount.as<uint32_t>());
-        hipLaunchKernelGGL(pb_wavetile_kernel, grid2d(((uint64_t)t->B * P2_WAVES + 255) / 256, 256), dim3(256), 0, nullptr, t->B,
-                           t->binPos, binTile.as<uint32_t>(), t->tl, dupCount.as<uint32_t>(), t->waveTile);
+        hipLaunchKernelGGL(pb_place_kernel, grid2d((nnz + 255) / 256, 256), dim3(256), 0, nullptr, nnz, spay, skeys, t->S, t->B, t->bins,
+                           tileStart.as<uint32_t>(), bmStart.as<uint32_t>(), t->val, t->lcol, t->lrow);
+        if (t->det) {
+            // every wavefront walks a whole sub-bin: its cursor starts at the sub-bin's first tile
+            PB_TRY(hipMemcpyAsync(t->waveTile, binTile.p, (size_t)t->B * 4, hipMemcpyDeviceToDevice, nullptr));
+        } else {
+            TempBuf dupCount;
+            if (dupCount.alloc((size_t)t->B * P2_WAVES * 4)) return fail("run-count workspace");
+            PB_TRY(hipMemsetAsync(dupCount.p, 0, (size_t)t->B * P2_WAVES * 4, nullptr));
+            hipLaunchKernelGGL(pb_dupcount_kernel, grid2d((nnz + 255) / 256, 256), dim3(256), 0, nullptr, t->B, nnz, t->binPos, t->lrow,
+                               dupCount.as<uint32_t>());
+            hipLaunchKernelGGL(pb_wavetile_kernel, grid2d(((uint64_t)t->B * P2_WAVES + 255) / 256, 256), dim3(256), 0, nullptr, t->B,
+                               t->binPos, binTile.as<uint32_t>(), t->tl, dupCount.as<uint32_t>(), t->waveTile);
+            PB_TRY(hipGetLastError());
+            PB_TRY(hipDeviceSynchronize());          // dupCount goes out of scope
+        }
         PB_TRY(hipGetLastError());
         PB_TRY(hipDeviceSynchronize());
     }
-    t->bytes = nnz * 12 + ((size_t)t->nList + TL_PAD) * 8 + ((size_t)t->B + 1) * 4 + (size_t)t->B * P2_WAVES * 4;
+    t->bytes = slabBytes + ((size_t)t->nList + TL_PAD) * 8 + ((size_t)t->B + 1) * 4 + (size_t)t->B * (t->det ? 1 : P2_WAVES) * 4;
 
     // phase-1 work list from the slice boundaries (tileStart[s*B])
     std::vector<uint32_t> sliceStart(t->S + 1);
@@ -875,6 +990,9 @@ int buildTiles(DevMat* d, const spmvTilesOpts* opts) {
     PB_TRY(hipFuncSetAttribute((const void*)pb_reduce_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, PB_R_MAX * 8));
     PB_TRY(hipFuncSetAttribute((const void*)pb_reduce_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, PB_R_MAX * 8));
     PB_TRY(hipFuncSetAttribute((const void*)pb_reduce_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, PB_R_MAX * 8));
+    PB_TRY(hipFuncSetAttribute((const void*)pb_reduce_det_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, PB_R_MAX * 8));
+    PB_TRY(hipFuncSetAttribute((const void*)pb_reduce_det_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, PB_R_MAX * 8));
+    PB_TRY(hipFuncSetAttribute((const void*)pb_reduce_det_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, PB_R_MAX * 8));
     // products that fit the Infinity Cache (with room for x and the streams) are stored with the default policy so
     // that phase 2 finds them there; larger streams bypass it (microbench_mall.hip: resident 7.0 vs 5.8 TB/s with
     // non-temporal stores; non-resident 4.9 vs 5.1-5.4)
@@ -896,13 +1014,14 @@ void tilesInfo(const DevMat* d, spmvTilesInfo* out) {
     memset(out, 0, sizeof *out);
     const TileFormat* t = d->tiles;
     if (!t) return;
-    out->nBins = t->B; out->rowsPerBin = t->R; out->nSlices = t->S; out->taper = t->bins.n1 != 0; out->ntStore = t->ntStore;
+    out->nBins = t->apiBins(); out->rowsPerBin = t->apiRows(); out->nSlices = t->S; out->taper = t->bins.n1 != 0; out->ntStore = t->ntStore;
     out->chunk = t->chunk; out->buildMs = t->buildMs; out->bytes = t->bytes; out->allocMs = t->allocMs;
+    out->tempBytes = t->tempBytes; out->deterministic = t->det ? 1 : 0;
 }
 
 void tilesShape(const DevMat* d, uint32_t* bins, uint32_t* rowsPerBin) {
-    *bins = d->tiles ? d->tiles->B : 0;
-    *rowsPerBin = d->tiles ? d->tiles->R : 0;
+    *bins = d->tiles ? d->tiles->apiBins() : 0;
+    *rowsPerBin = d->tiles ? d->tiles->apiRows() : 0;
 }
 
 // phase 1 on `stream`: products of the whole matrix into the format's workspace
@@ -926,7 +1045,7 @@ int enqueueTilesExpand(DevMat* d, const double* x, hipStream_t stream) {
 // to the nExtra further destinations (same row indexing)
 int enqueueTilesReduce(DevMat* d, uint32_t binBegin, uint32_t binEnd, double* y, int nExtra, double* const* extra, hipStream_t stream) {
     TileFormat* t = d->tiles;
-    if (!t || binBegin > binEnd || binEnd > t->B || nExtra < 0 || nExtra > SPMV_MAX_PEERS) return EXIT_FAILURE;
+    if (!t || binBegin > binEnd || binEnd > t->apiBins() || nExtra < 0 || nExtra > SPMV_MAX_PEERS) return EXIT_FAILURE;
     if (binBegin == binEnd) return EXIT_SUCCESS;
     const dim3 grid = grid2d((uint64_t)((binEnd - binBegin + 7) / 8) * 8, PB_THREADS);
     const double* prod = prodWorkspace(t->nnz, false);
@@ -935,6 +1054,16 @@ int enqueueTilesReduce(DevMat* d, uint32_t binBegin, uint32_t binEnd, double* y,
     dst.n = (uint32_t)nExtra;
     for (int i = 0; i < nExtra; ++i) dst.p[i] = extra[i];
     const TileSignal none{nullptr, 0};
+    if (t->det) {
+        const size_t lds = (size_t)8 * t->apiRows();
+        if (nExtra)
+            hipLaunchKernelGGL(pb_reduce_det_kernel<1>, grid, dim3(PD_THREADS), lds, stream, t->bins, t->B, binBegin, binEnd, d->M, t->binPos,
+                               t->waveTile, t->tl, prod, t->lrow, y, dst, none);
+        else
+            hipLaunchKernelGGL(pb_reduce_det_kernel<0>, grid, dim3(PD_THREADS), lds, stream, t->bins, t->B, binBegin, binEnd, d->M, t->binPos,
+                               t->waveTile, t->tl, prod, t->lrow, y, dst, none);
+        return hipGetLastError() == hipSuccess ? EXIT_SUCCESS : EXIT_FAILURE;
+    }
     if (nExtra)
         hipLaunchKernelGGL(pb_reduce_kernel<1>, grid, dim3(PB_THREADS), (size_t)8 * t->R, stream,
                            t->bins, binBegin, binEnd, d->M, t->binPos, t->waveTile, t->tl, prod, t->lrow, y, dst, none);
@@ -953,10 +1082,11 @@ int enqueueTilesReducePush(DevMat* d, double* y, int nExtra, double* const* extr
     if (!t || nExtra < 1 || nExtra > SPMV_MAX_PEERS) return EXIT_FAILURE;
     const double* prod = prodWorkspace(t->nnz, true);
     if (!prod || prodHandover(stream)) return EXIT_FAILURE;
+    const uint32_t nb = t->apiBins();
     if (!t->ready) {
-        if (hipMalloc(&t->ready, ((size_t)t->B + 1) * 4) != hipSuccess) return EXIT_FAILURE;
-        if (hipMemset(t->ready, 0, ((size_t)t->B + 1) * 4) != hipSuccess) return EXIT_FAILURE;   // [B] doubles as the failure word
-        t->pushFail = t->ready + t->B;
+        if (hipMalloc(&t->ready, ((size_t)nb + 1) * 4) != hipSuccess) return EXIT_FAILURE;
+        if (hipMemset(t->ready, 0, ((size_t)nb + 1) * 4) != hipSuccess) return EXIT_FAILURE;   // [nb] doubles as the failure word
+        t->pushFail = t->ready + nb;
     }
     const uint32_t epoch = ++t->epoch ? t->epoch : ++t->epoch;             // never 0 (the initial flag value)
     TileDst dst{};
@@ -964,10 +1094,14 @@ int enqueueTilesReducePush(DevMat* d, double* y, int nExtra, double* const* extr
     for (int i = 0; i < nExtra; ++i) dst.p[i] = extra[i];
     const TileSignal sig{t->ready, epoch};
     if (hipEventRecord(evFork, stream) != hipSuccess || hipStreamWaitEvent(side, evFork, 0) != hipSuccess) return EXIT_FAILURE;
-    hipLaunchKernelGGL(pb_push_kernel, dim3(std::min<uint32_t>(PUSH_WGS, t->B)), dim3(PUSH_THREADS), 0, side, t->bins, t->B, d->M, t->ready,
+    hipLaunchKernelGGL(pb_push_kernel, dim3(std::min<uint32_t>(PUSH_WGS, nb)), dim3(PUSH_THREADS), 0, side, t->apiMap(), nb, d->M, t->ready,
                        epoch, y, dst, t->pushFail);
-    hipLaunchKernelGGL(pb_reduce_kernel<2>, grid2d((uint64_t)((t->B + 7) / 8) * 8, PB_THREADS), dim3(PB_THREADS), (size_t)8 * t->R, stream,
-                       t->bins, 0u, t->B, d->M, t->binPos, t->waveTile, t->tl, prod, t->lrow, y, TileDst{}, sig);
+    if (t->det)
+        hipLaunchKernelGGL(pb_reduce_det_kernel<2>, grid2d((uint64_t)((nb + 7) / 8) * 8, PB_THREADS), dim3(PD_THREADS), (size_t)8 * t->apiRows(), stream,
+                           t->bins, t->B, 0u, nb, d->M, t->binPos, t->waveTile, t->tl, prod, t->lrow, y, TileDst{}, sig);
+    else
+        hipLaunchKernelGGL(pb_reduce_kernel<2>, grid2d((uint64_t)((t->B + 7) / 8) * 8, PB_THREADS), dim3(PB_THREADS), (size_t)8 * t->R, stream,
+                           t->bins, 0u, t->B, d->M, t->binPos, t->waveTile, t->tl, prod, t->lrow, y, TileDst{}, sig);
     if (hipEventRecord(evJoin, side) != hipSuccess) return EXIT_FAILURE;          // the caller joins (tilesPushJoin) when it needs y delivered
     return hipGetLastError() == hipSuccess ? EXIT_SUCCESS : EXIT_FAILURE;
 }
@@ -986,7 +1120,7 @@ int enqueueTiles(DevMat* d, const double* x, double* y, hipStream_t stream) {
     TileFormat* t = d->tiles;
     if (!t) return EXIT_FAILURE;
     if (enqueueTilesExpand(d, x, stream)) return EXIT_FAILURE;
-    return enqueueTilesReduce(d, 0, t->B, y, 0, nullptr, stream);
+    return enqueueTilesReduce(d, 0, t->apiBins(), y, 0, nullptr, stream);
 }
 
 }  // namespace spmvhip

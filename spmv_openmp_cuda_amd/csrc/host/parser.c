@@ -20,6 +20,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <sys/stat.h>
 
 #include "parser.h"
 #include "sparseMatrix.h"
@@ -136,7 +137,25 @@ MatrixMarket* MMRead(char* matPath) {
     if (MMCheck(out->mcode)) goto fail;
     if (mm_read_mtx_crd_size(fp, &out->M, &out->N, &out->NZ)) { fprintf(stderr, "mm_read_mtx_crd_size err at %s:\n", matPath); goto fail; }
     if (!(out->rowLens = calloc(out->M ? out->M : 1, sizeof *out->rowLens))) { ERRPRINT("MMRead:\trowLens calloc errd\n"); goto fail; }
-    {   /* bounds are checked while parsing: wrap rowLens access */
+    {   /* fast path: the rest of a regular file goes to memory and is parsed by all cores (mmfast.c) */
+        struct stat st;
+        const long pos = ftell(fp);
+        if (pos >= 0 && fstat(fileno(fp), &st) == 0 && S_ISREG(st.st_mode) && (long)st.st_size >= pos) {
+            const size_t len = (size_t)st.st_size - (size_t)pos;
+            char* buf = malloc(len + 1);
+            if (buf && fread(buf, 1, len, fp) == len) {
+                buf[len] = 0;
+                int status = 0;
+                out->entries = MMtoCOOFromBuffer(&out->NZ, buf, len, out->mcode, out->M, out->N, out->rowLens, &status);
+                free(buf);
+                if (out->entries) { fclose(fp); return out; }
+                if (status != MMFAST_FALLBACK) { ERRPRINTS("MAT PARSE TO CSR ERR at:%s\n", matPath); goto fail; }
+                memset(out->rowLens, 0, (out->M ? out->M : 1) * sizeof *out->rowLens);
+            } else free(buf);
+            if (fseek(fp, pos, SEEK_SET)) { perror("fseek"); goto fail; }
+        }
+    }
+    {   /* serial path (pipes, odd layouts): bounds are checked in a first pass, the entries read in a second */
         const ulong M = out->M, N = out->N;
         long pos = ftell(fp);
         ulong r, c; double v; int ok = 1;

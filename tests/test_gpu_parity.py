@@ -793,6 +793,96 @@ def test_stripes_deterministic_form_is_the_serial_order(api, oracle, name):
     assert np.array_equal(np.concatenate(parts), ys[0])
 
 
+@pytest.mark.parametrize("name", list(CASES))
+def test_tiles_deterministic_form_is_the_serial_order(api, oracle, name):
+    """spmvTilesOpts.deterministic: a bin is four sub-bins, each walked by ONE wavefront in bin-major order, so a row's
+    products are added in ascending column order: y is the same bits in every run, for every bin height (automatic, 256,
+    5000 rows), when the rows are computed as three separate row blocks (the shape of a 3-rank run), through the
+    expand / reduce pair with bin ranges, and it is the bits of the serial oracle."""
+    import ctypes as C
+    M, N, IRP, JA, AS = CASES[name]
+    if JA.size == 0:
+        pytest.skip("the two-phase format needs at least one entry")
+    x = _x(np.random.default_rng(37), N)
+    y_ref = oracle.csr_serial(IRP, JA, AS, x)
+    dmat = api.spMatCpyCSR(api.HostCSR(M, N, IRP, JA, AS))
+    ys = []
+    for rows in (0, 256, 5000, 0):
+        api.build_tiles(dmat, rowsPerBin=rows, deterministic=True)
+        info = api.tiles_info(dmat)
+        assert info.deterministic == 1 and info.rowsPerBin % 4 == 0 and info.nBins == (M + info.rowsPerBin - 1) // info.rowsPerBin
+        for _ in range(3):
+            ys.append(_run(api, "hipSpMVTilesCSR", dmat, x, M))
+    # the two phases as separate launches, phase 2 in three bin ranges
+    nb = api.tiles_info(dmat).nBins
+    dx, dy = api.DeviceVector(N).up(x), api.DeviceVector(M)
+    dy.poison()
+    assert api.lib.hipSpMVTilesExpand(C.byref(dmat.handle), dx.ptr) == 0
+    for b0, b1 in ((0, nb // 3), (nb // 3, nb // 3), (nb // 3, nb)):
+        assert api.lib.hipSpMVTilesReduce(C.byref(dmat.handle), b0, b1, dy.ptr, 0, None) == 0
+    ys.append(dy.down())
+    with pytest.raises(api.SpmvHipError):
+        api.build_tiles(dmat, taper=True, deterministic=True)
+    dmat.free()
+    for y in ys:
+        assert np.array_equal(y, ys[0])
+    assert np.array_equal(ys[0], y_ref)
+    cuts = [0, M // 3, 2 * M // 3, M]
+    parts = []
+    for r0, r1 in zip(cuts[:-1], cuts[1:]):
+        if r1 == r0:
+            continue
+        b0, b1 = int(IRP[r0]), int(IRP[r1])
+        if b1 == b0:
+            parts.append(np.zeros(r1 - r0))
+            continue
+        blk = api.spMatCpyCSR(api.HostCSR(r1 - r0, N, IRP[r0:r1 + 1] - IRP[r0], JA[b0:b1], AS[b0:b1]))
+        api.build_tiles(blk, deterministic=True)
+        parts.append(_run(api, "hipSpMVTilesCSR", blk, x, r1 - r0))
+        blk.free()
+    assert np.array_equal(np.concatenate(parts), ys[0])
+
+
+@pytest.mark.parametrize("key", ["c3", "c5"])
+def test_deterministic_forms_at_full_size(api, oracle, key):
+    """BASELINE's full sizes through the deterministic forms of the two fast kernels: five runs give the same bits, the
+    windows (head, middle, tail, heaviest row) are the serial oracle's bits, and the two kernels agree with each other on
+    every row (both sum in ascending column order)."""
+    from spmv_openmp_cuda_amd import synth
+    w = synth.WORKLOADS[key]
+    lens = synth.row_lengths(w)
+    irp = synth.prefix(lens)
+    dm = synth.device_csr(w, irp, 0, w.N)
+    x = synth.make_x(w.N, w.cfg)
+    dx, dy = api.DeviceVector(w.N).up(x), api.DeviceVector(w.N)
+    S = 100_000
+    heavy = int(np.argmax(lens))
+    ranges = [(0, S), (w.N // 2, w.N // 2 + S), (w.N - S, w.N), (max(0, heavy - 10), min(w.N, heavy + 10))]
+    refs = []
+    for r0, r1 in ranges:
+        ja, as_ = oracle.synth_fill(w.N, r0, irp[r0:r1 + 1], synth.SEED_STRUCT + w.cfg, synth.SEED_VAL + w.cfg, w.band)
+        refs.append(oracle.csr_serial_dev((irp[r0:r1 + 1] - irp[r0]).astype(np.uint32), ja, as_, x))
+    results = {}
+    for launcher, build in (("hipSpMVTilesCSR", api.build_tiles),) + ((("hipSpMVStripesCSR", api.build_stripes),) if key == "c3" else ()):
+        build(dm, deterministic=True)
+        first = None
+        for _ in range(5):
+            dy.poison()
+            api.spmv(launcher, dm, dx, dy)
+            y = dy.down()
+            if first is None:
+                first = y
+                assert not np.isnan(y).any()
+                for (r0, r1), yr in zip(ranges, refs):
+                    assert np.array_equal(y[r0:r1], yr), (launcher, r0)
+            else:
+                assert np.array_equal(y, first), launcher
+        results[launcher] = first
+    if len(results) == 2:
+        assert np.array_equal(results["hipSpMVTilesCSR"], results["hipSpMVStripesCSR"])
+    dm.free()
+
+
 def test_tiles_build_options(api, oracle):
     """spmvHipBuildTilesOpt: options are arguments of the build (no process state), an explicit build replaces the format,
     out-of-range options are refused, and spmvHipTilesInfo reports what was built."""
@@ -805,7 +895,8 @@ def test_tiles_build_options(api, oracle):
     for rows, chunk, nt in ((0, 0, -1), (128, 4096, 0), (4096, 65536, 1), (0, 0, -1)):
         api.build_tiles(dmat, rowsPerBin=rows, chunk=chunk, ntStore=nt)
         info = api.tiles_info(dmat)
-        assert info.nBins >= 1 and info.buildMs > 0 and info.bytes > 0
+        assert info.nBins >= 1 and info.buildMs > 0 and info.bytes > 0 and info.deterministic == 0
+        assert 0 < info.tempBytes <= 13 * JA.size + 24 * info.nSlices * info.nBins + (1 << 20)      # 12 B per entry + the tile tables
         if rows:
             assert info.rowsPerBin == rows and info.nBins == (M + rows - 1) // rows
         if chunk:
