@@ -21,14 +21,6 @@ $(PKG)/lib/libspmvhip.so: $(HIPSRC) $(HIPHDR)
 	mkdir -p $(PKG)/lib
 	$(HIPCC) $(HIPFLAGS) -o $@ $(HIPSRC)
 
-# tuning builds of the GPU library (loaded through SPMV_LIB by the scripts; never shipped):
-#   make dbglib                                   stripes kernel with progress stamps (scripts/stripes_drift.py)
-#   make tunelib TUNE_NAME=g1 TUNE_DEFS=-DSPMV_SB_GATHER=1
-dbglib:
-	$(HIPCC) $(HIPFLAGS) -DSPMV_SB_DEBUG $(TUNE_DEFS) -o $(PKG)/lib/libspmvhip_dbg.so $(HIPSRC)
-tunelib:
-	$(HIPCC) $(HIPFLAGS) $(TUNE_DEFS) -o $(PKG)/lib/libspmvhip_$(TUNE_NAME).so $(HIPSRC)
-
 host: $(PKG)/lib/libspmvhost.so $(PKG)/bin/SpMV_HIP.elf
 $(PKG)/lib/libspmvhost.so: $(HOSTLIBSRC) $(wildcard include/*.h)
 	mkdir -p $(PKG)/lib
@@ -48,4 +40,4 @@ tests/harness/test_SpMV_HIP.elf: tests/harness/spmv_test.c oracle $(PKG)/lib/lib
 clean:
 	rm -f $(PKG)/lib/*.so $(PKG)/bin/*.elf tests/harness/*.elf
 	$(MAKE) -C oracle clean
-.PHONY: all lib dbglib tunelib host oracle harness clean
+.PHONY: all lib host oracle harness clean

@@ -55,6 +55,9 @@ def parse():
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-extra", action="store_true", help="skip the secondary workloads measured at N=1")
     p.add_argument("--cpu-sample-nnz", type=int, default=100_000_000)
+    p.add_argument("--only-structured", default="",
+                   help="measure only the structured stand-in whose name contains this string (stencil3d, road, blocks; 'all' = the "
+                        "three) and print that block alone -- for profiling the ELL / CSR kernels on the reference's kind of matrix")
     p.add_argument("--groups", type=int, default=0, help="pin the row groups per rank of the exchange at N > 1")
     p.add_argument("--pieces", type=int, default=0, help="pin the pieces of y per rank for --exchange push")
     p.add_argument("--exchange", default="auto", choices=["auto", "rccl", "push", "fused", "auto-no-rccl"],
@@ -241,6 +244,9 @@ def measure_single(api, synth, torch, w, launcher, steps, warmup, candidates=Non
         "algorithmic_bytes": bytes_alg,
     })
     res.update(format_info(api, dm, launcher))
+    if launcher == "hipSpMVRowsCSR" and _ROWS_VARIANT[0] == 2:
+        nm = api.lib.spmvHipAutoChoiceRows(C.byref(dm.handle), None)
+        res["launcher_resolved_to"] = nm.decode() if nm else None
     if launcher == "hipSpMVTilesCSR":
         res["kernel_ms_phases"] = tiles_phase_ms(api, torch, dm, x.data_ptr(), y.data_ptr())
     return res, dict(dm=dm, irp=irp, x_host=x_host, y=y, x=x, lens=lens)
@@ -332,6 +338,53 @@ def cpu_model():
     except OSError:
         pass
     return "unknown"
+
+
+_CPUS = {}
+
+
+def effective_cpus():
+    """CPUs this process may really use: the affinity mask capped by the cgroup's CPU quota (a container on a 128-thread
+    host is often entitled to far fewer: a parallel region with one thread per visible CPU then shares a few cores).
+    Taken ONCE, at start-up: once libgomp has bound the calling thread to its place the mask shows that place only."""
+    if _CPUS:
+        return dict(_CPUS)
+    aff = len(os.sched_getaffinity(0))
+    quota = None
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:                 # cgroup v2: "<quota|max> <period>"
+            q, period = f.read().split()
+            if q != "max":
+                quota = float(q) / float(period)
+    except (OSError, ValueError):
+        try:
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f, open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as g:
+                q, period = float(f.read()), float(g.read())
+                if q > 0:
+                    quota = q / period
+        except (OSError, ValueError):
+            pass
+    eff = aff if quota is None else max(1, min(aff, int(quota + 0.5)))
+    _CPUS.update({"affinity_cpus": aff, "cgroup_cpu_quota": quota, "effective_cpus": eff})
+    return dict(_CPUS)
+
+
+def cpu_sanity(ora, irp64, as_, rows):
+    """what the OpenMP runtime really gives a parallel region here, and a gather-free streaming figure on the same arrays
+    (row sums of AS under the same static partition: 8 B per entry + 16 B per row)"""
+    import numpy as np
+    vp = C.c_void_p
+    ora.oracleRowSumSeconds.restype = C.c_double
+    ora.oracleRowSumSeconds.argtypes = [C.c_ulong, vp, vp, vp]
+    y = np.empty(rows)
+    nnz = int(irp64[rows])
+    ts = [ora.oracleRowSumSeconds(rows, irp64.ctypes.data_as(vp), as_.ctypes.data_as(vp), y.ctypes.data_as(vp)) for _ in range(4)]
+    t = min(ts[1:])
+    out = dict(effective_cpus())
+    out.update({"threads_in_region": int(ora.oracleThreadsInRegion()), "distinct_cpus_in_region": int(ora.oracleDistinctCpusInRegion()),
+                "stream_like_gbps": (nnz * 8 + rows * 16) / t * 1e-9,
+                "stream_like_note": "row sums of AS, no gather: 8 B per entry + 16 B per row, best of 3 passes, same static partition"})
+    return out
 
 
 def cpu_baseline(synth, w, irp, x_host, rows, iters=5):
@@ -432,6 +485,14 @@ def cpu_baseline(synth, w, irp, x_host, rows, iters=5):
         t_static = t_static[1:]
     t = sum(t_static) / len(t_static)
     avg, var = (lambda v: (float(np.mean(v)), float(np.var(v))))(np.array(t_static))
+    out.update(cpu_sanity(ora, irp_s, as_, rows))
+    out["value_is_sample"] = bool(rows != w.N)
+    # how the figure is to be read: a CSR SpMV with uniformly spread columns pays one cache-missing 64-B line of x per
+    # entry on top of the 16 B/entry stream, so it is latency-bound (threads x misses in flight / memory latency), far
+    # below the streaming figure beside it
+    out["gather_bound_note"] = (f"{2.0 * nnz_s / t * 1e-9 / 2:.2f} G entries/s on {out['threads_in_region']} threads = "
+                                f"{nnz_s / t / max(out['threads_in_region'], 1) * 1e-6:.1f} M x-gathers/s per thread; the gather-free "
+                                f"stream over the same arrays runs at {out['stream_like_gbps']:.0f} GB/s")
     out.update({"value": 2.0 * nnz_s / t * 1e-9, "cores": cores, "kind": kind,
                 "sample": f"rows [0,{rows}) of {w.name} = {nnz_s} nnz ({'the whole matrix' if rows == w.N else 'a head sample'}), x full "
                           f"length, {len(t_static)} timed passes of spmvRowsBasicCSR after one page-in pass, OMP schedule static, matrix "
@@ -441,12 +502,96 @@ def cpu_baseline(synth, w, irp, x_host, rows, iters=5):
     return out, y_cpu
 
 
+def cpu_baseline_ell_c4(synth, w, irp, x_host, rows, K):
+    """The reference's spmvRowsBasicELL (src/SpMV_ELL_OMP.c:33-67; oracle/_ref, or the oracle port) beside the GPU's ELL
+    kernels of config 4: rows [0, rows) of the clipped matrix as the loader would hold them (row-major, 64-bit indices,
+    {0, 0.0} padding, row lengths), static schedule, and spmvRowsBasicCSR on the same rows for comparison."""
+    import numpy as np
+    from spmv_openmp_cuda_amd.ctypes_defs import ref_CONFIG, ref_spmat
+    vp = C.c_void_p
+    ora = C.CDLL(os.path.join(ROOT, "oracle", "liboracle.so"))
+    ora.synthFillCsrRef.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64, vp, vp, vp, C.c_uint64, C.c_uint64, C.c_uint64]
+    ora.oracleCsrSerial.argtypes = [C.c_ulong, vp, vp, vp, vp, vp]
+    irp_s = np.ascontiguousarray(irp[:rows + 1], dtype=np.uint64)
+    nnz_s = int(irp_s[-1])
+    ja32, as_ = np.empty(nnz_s, dtype=np.uint32), np.empty(nnz_s)
+    ora.synthFillCsrRef(rows, w.N, 0, irp_s.ctypes.data_as(vp), ja32.ctypes.data_as(vp), as_.ctypes.data_as(vp),
+                        synth.SEED_STRUCT + w.cfg, synth.SEED_VAL + w.cfg, w.band)
+    ja64 = ja32.astype(np.uint64)
+    lens = np.diff(irp_s.astype(np.int64))
+    eja, eas = np.zeros((rows, K), dtype=np.uint64), np.zeros((rows, K))
+    r_of = np.repeat(np.arange(rows), lens)
+    pos = np.arange(nnz_s) - np.repeat(irp_s[:-1].astype(np.int64), lens)
+    eja[r_of, pos] = ja64
+    eas[r_of, pos] = as_
+    del r_of, pos
+    rl = lens.astype(np.uint64)
+    y_ref = np.empty(rows)
+    ora.oracleCsrSerial(rows, irp_s.ctypes.data_as(vp), ja64.ctypes.data_as(vp), as_.ctypes.data_as(vp), x_host.ctypes.data_as(vp), y_ref.ctypes.data_as(vp))
+    ref_path = os.path.join(ROOT, "oracle", "_ref", "libspmvref.so")
+    kind = "reference" if os.path.exists(ref_path) else "port"
+    lib = C.CDLL(ref_path) if kind == "reference" else ora
+    (lib.refSetSchedule if kind == "reference" else ora.oracleSetSchedule)(1, 0)
+    cfg = ref_CONFIG()
+    cfg.gridRows = cfg.gridCols = 8
+    cfg.threadNum = int((lib.refMaxThreads if kind == "reference" else ora.oracleMaxThreads)())
+    if kind == "reference":
+        lib.refChunksNOOP.restype = vp
+        cfg.chunkDistrbFunc = lib.refChunksNOOP()
+
+    def mat(ell):
+        m = ref_spmat()                              # (this repo's spmat starts with the same fields: the port reads it alike)
+        m.M, m.N, m.NZ, m.MAX_ROW_NZ = rows, w.N, nnz_s, K if ell else 0
+        m.JA = (eja if ell else ja64).ctypes.data_as(C.POINTER(C.c_ulong))
+        m.AS = (eas if ell else as_).ctypes.data_as(C.POINTER(C.c_double))
+        m.RL = rl.ctypes.data_as(C.POINTER(C.c_ulong))
+        if not ell:
+            m.IRP = irp_s.ctypes.data_as(C.POINTER(C.c_ulong))
+        return m
+    out = {"kind": kind, "cores": int(cfg.threadNum), "unit": "GFLOP/s", "schedule": "static",
+           "sample": f"rows [0,{rows}) of {w.name}: {nnz_s} nnz in {rows} x {K} slots, 3 timed passes after one page-in pass", **effective_cpus()}
+    if kind == "port":                               # the port's functions take this repo's (longer) struct: same prefix, pad the tail
+        from spmv_openmp_cuda_amd.ctypes_defs import spmat as own_spmat
+
+        def widen(m):
+            o = own_spmat()
+            for f, _ in ref_spmat._fields_:
+                setattr(o, f, getattr(m, f))
+            return o
+    for label, fn, ell in (("spmvRowsBasicELL (row lengths)", lib.spmvRowsBasicELL, True), ("spmvRowsBasicCSR", lib.spmvRowsBasicCSR, False)):
+        fn.argtypes = [vp, vp, vp, vp]
+        m = mat(ell)
+        if kind == "port":
+            m = widen(m)
+        y = np.empty(rows)
+        ts = []
+        for _ in range(4):
+            y[:] = np.nan
+            t0 = time.perf_counter()
+            rc = fn(C.byref(m), x_host.ctypes.data_as(vp), C.byref(cfg), y.ctypes.data_as(vp))
+            ts.append(time.perf_counter() - t0)
+            if rc or not np.all(np.abs(y - y_ref) <= GATE):
+                raise SystemExit(f"CPU baseline {label} failed the gate on {w.name}")
+        out[label] = {"gflops": 2.0 * nnz_s / (sum(ts[1:]) / 3) * 1e-9, "pass_seconds_avg": sum(ts[1:]) / 3}
+    log(f"c4 CPU ({kind}, {cfg.threadNum} threads, {rows} rows): ELL {out['spmvRowsBasicELL (row lengths)']['gflops']:.2f}  CSR {out['spmvRowsBasicCSR']['gflops']:.2f} GFLOP/s")
+    return out
+
+
 def full_rows_parity(y_cpu, y_gpu_head):
     import numpy as np
     d = np.abs(y_cpu - y_gpu_head)
     nan = bool(np.isnan(y_gpu_head).any())
     return {"rows_checked": int(y_cpu.size), "max_abs_diff": float(np.nanmax(d)), "nan_in_gpu_y": nan,
             "ok": bool(not nan and np.nanmax(d) <= GATE)}
+
+
+_ROWS_VARIANT = [1]
+
+
+def set_rows_variant(api, v):
+    """hipSpMVRowsCSR: 1 = the LDS-stream kernel by name, 2 = the library default (fastest serial-order kernel)"""
+    api.set_variant("hipSpMVRowsCSR", v)
+    _ROWS_VARIANT[0] = v
 
 
 def measure_block(api, synth, torch, w, launcher, steps, warmup, candidates=None, cpu_rows=0):
@@ -483,6 +628,25 @@ def measure_block(api, synth, torch, w, launcher, steps, warmup, candidates=None
                                           "ms": dict(zip(("hipSpMVWarpPerRowCSR", "hipSpMVTilesCSR", "hipSpMVStripesCSR"), [float(v) for v in ms3]))}
             if not par2["ok"]:
                 raise SystemExit(f"PARITY FAILURE on {w.name} [hipSpMVAutoCSR -> {name}]: {par2}")
+    if res["auto_candidates_ms"] and hasattr(api.lib, "spmvHipAutoChoiceRows"):
+        # ... and what the serial-order default of hipSpMVRowsCSR (variant 2: LDS-stream kernel / deterministic two-phase /
+        # deterministic stripes) resolves to and costs on this matrix: every candidate must give the serial oracle's BITS
+        keep = _ROWS_VARIANT[0]
+        set_rows_variant(api, 2)
+        try:
+            y_t.fill_(float("nan"))
+            if api.lib.hipSpMVRowsCSR(C.byref(ctx["dm"].handle), ctx["x"].data_ptr(), api.CONFIG(), y_t.data_ptr()) == 0:
+                torch.cuda.synchronize()
+                ms3 = (C.c_double * 3)()
+                name = api.lib.spmvHipAutoChoiceRows(C.byref(ctx["dm"].handle), ms3)
+                par3 = win.check(lambda a, b: y_t[a:b].cpu().numpy(), bitwise=True)
+                res["library_serial_order_choice"] = {
+                    "launcher": name.decode() if name else None, "bit_identical_to_serial_oracle": bool(par3["ok"]),
+                    "ms": dict(zip(("hipSpMVRowsCSR(LDS-stream)", "hipSpMVTilesCSR(deterministic)", "hipSpMVStripesCSR(deterministic)"), [float(v) for v in ms3]))}
+                if not par3["ok"]:
+                    raise SystemExit(f"PARITY FAILURE on {w.name} [hipSpMVRowsCSR variant 2 -> {name}]: {par3}")
+        finally:
+            set_rows_variant(api, keep)
     ctx["dm"].free()
     del ctx
     torch.cuda.empty_cache()
@@ -542,6 +706,8 @@ def measure_c4(api, synth, torch, args, steps, warmup):
         run("ELL row-major, lanes per row (wavefront-per-row family)", "hipSpMVWarpsPerRowELLNTrasposed", ell, rl, b_csr if rl else b_ell)
     ell.free()
     api.lib.spmvHipSetEllRowLens(1)
+    if not args.no_cpu_baseline:
+        out["cpu_baseline_ell"] = cpu_baseline_ell_c4(synth, w, irp, x_host, min(M, 2_000_000), K)
     # the size guard on the UNCLIPPED matrix (10 M rows x 50 k slots): refused through the C-ABI before any allocation
     w3 = synth.WORKLOADS["c3"] if args.scale == 1.0 else synth.scaled(synth.WORKLOADS["c3"], args.scale)
     irp3 = synth.prefix(synth.row_lengths(w3))
@@ -554,6 +720,202 @@ def measure_c4(api, synth, torch, args, steps, warmup):
     if args.scale == 1.0 and rc == 0:
         raise SystemExit("the ELL size guard accepted the unclipped power-law matrix")
     torch.cuda.empty_cache()
+    return out
+
+
+# ------------------------------------------------------------------------------------------------- structured matrices
+# The matrices the reference's report publishes numbers for are structured SuiteSparse matrices (matrix list
+# doc/relazione.tex:463); the files cannot be fetched here, so stand-ins with the same SHAPE are generated
+# (csrc/host/structured.c), written as MatrixMarket files and taken through the loader (MMtoCSR / MMtoELL), the uploads
+# (spMatCpyCSR / ellTranspose + spMatCpyELL) and every launcher -- the path a user of the reference's CLI walks.
+# `published`: what the reference's tables show for the matrix the stand-in is shaped after (unstated GPU, probably a
+# Quadro RTX 5000 with 448 GB/s; "CSR 1" / "ELL 2" columns are invalid there -- rows 0..31 only, BASELINE.md caveat 1).
+STRUCTURED = (
+    {"name": "stencil3d-500x100x100", "kind": 0, "p": (500, 100, 100), "after": "channel-500x100x100-b050 (4.8 M rows, 85.4 M nnz, max row 18)",
+     "published": {"CUDA ELL 0 (transposed, thread per row)": "3.86e-3 s = 44.25 GFLOP/s", "CUDA ELL 1 (row-major, thread per row)": "9.04e-3 s = 18.9 GFLOP/s",
+                   "OMP ELL 0 spmvRowsBasicELL": "2.81e-2 s = 6.1 GFLOP/s"}},
+    {"name": "road-12M", "kind": 1, "p": (12_000_000, 0, 0), "after": "asia_osm (11.95 M rows, 25.4 M nnz, max row 9)",
+     "published": {"CUDA CSR 0 (thread per row)": "2.13e-3 s = 23.87 GFLOP/s", "OMP CSR 1 spmvRowsBasicCSR": "3.09e-2 s = 1.6 GFLOP/s"}},
+    {"name": "blocks-36k", "kind": 2, "p": (36_417, 24, 0), "after": "pdb1HYS (36 417 rows, 4.34 M nnz, max row 204)",
+     "published": {"CUDA CSR 0 (thread per row)": "1.04e-3 s = 8.4 GFLOP/s", "CUDA CSR 1 (warp per row)": "8.92e-5 s = 97.42 GFLOP/s (INVALID: rows 0..31 only)"}},
+)
+
+
+def scratch_dir():
+    for d in ("/dev/shm", os.environ.get("TMPDIR", ""), "/tmp"):
+        if d and os.path.isdir(d) and os.access(d, os.W_OK):
+            return d
+    return "."
+
+
+def measure_structured(api, synth, torch, args, steps, warmup, only=""):
+    import numpy as np
+    from spmv_openmp_cuda_amd.ctypes_defs import ref_CONFIG
+    H, vp = api.hostlib, C.c_void_p
+    ora = C.CDLL(os.path.join(ROOT, "oracle", "liboracle.so"))
+    ora.oracleCsrSerial.argtypes = [C.c_ulong, vp, vp, vp, vp, vp]
+    ref_path = os.path.join(ROOT, "oracle", "_ref", "libspmvref.so")
+    cpu = C.CDLL(ref_path) if os.path.exists(ref_path) else ora          # both export spmvRowsBasicCSR / spmvRowsBasicELL
+    cpu_kind = "reference" if cpu is not ora else "port"
+    for fn in (cpu.spmvRowsBasicCSR, cpu.spmvRowsBasicELL):
+        fn.argtypes = [vp, vp, vp, vp]
+    (cpu.refSetSchedule if cpu_kind == "reference" else ora.oracleSetSchedule)(1, 0)              # static
+    noop = (cpu.refChunksNOOP if cpu_kind == "reference" else None)
+    if noop is not None:
+        noop.restype = vp
+    out = {"note": "stand-ins shaped like the matrices of the reference's report, generated -> .mtx -> MMtoCSR/MMtoELL -> upload -> launchers; "
+                   "`published` = the reference's own tables for the original matrix (other, unstated hardware)", "matrices": []}
+    for spec in STRUCTURED:
+        if only and only != "all" and only not in spec["name"]:
+            continue
+        p0, p1, p2 = spec["p"]
+        if args.scale != 1.0:
+            p0 = max(8, int(p0 * args.scale))
+        path = os.path.join(scratch_dir(), f"spmv_bench_{os.getpid()}_{spec['name']}.mtx")
+        Mv, NZv, mxv = C.c_ulong(), C.c_ulong(), C.c_ulong()
+        blk = {"name": spec["name"], "shaped_after": spec["after"], "published_for_the_original": spec["published"], "runs": []}
+        csr = ell = ell_t = None
+        dms = []
+        try:
+            t0 = time.perf_counter()
+            if H.spmvSynthWriteMtx(path.encode(), spec["kind"], p0, p1, p2, 0x57A7 + spec["kind"], C.byref(Mv), C.byref(NZv), C.byref(mxv)):
+                raise RuntimeError("spmvSynthWriteMtx failed")
+            t1 = time.perf_counter()
+            csr = H.MMtoCSR(path.encode())
+            t2 = time.perf_counter()
+            ell = H.MMtoELL(path.encode())
+            t3 = time.perf_counter()
+            if not csr or not ell:
+                raise RuntimeError("the loader refused the generated file")
+            M, nnz, K = int(Mv.value), int(NZv.value), int(mxv.value)
+            m = csr.contents
+            assert (m.M, m.NZ) == (M, nnz) and ell.contents.MAX_ROW_NZ == K
+            blk.update({"M": M, "N": M, "nnz": nnz, "row_len_avg": nnz / M, "row_len_max": K, "mtx_bytes": os.path.getsize(path),
+                        "write_mtx_s": t1 - t0, "MMtoCSR_s": t2 - t1, "MMtoELL_s": t3 - t2,
+                        "loader_entries_per_s": nnz / (t2 - t1), "ell_padding_ratio_MK_over_nnz": M * K / nnz})
+            irp = np.ctypeslib.as_array(m.IRP, shape=(M + 1,))
+            ja = np.ctypeslib.as_array(m.JA, shape=(nnz,))
+            as_ = np.ctypeslib.as_array(m.AS, shape=(nnz,))
+            x_host = synth.make_x(M, 20 + spec["kind"])
+            y_ref = np.empty(M)
+            ora.oracleCsrSerial(M, irp.ctypes.data_as(vp), ja.ctypes.data_as(vp), as_.ctypes.data_as(vp), x_host.ctypes.data_as(vp), y_ref.ctypes.data_as(vp))
+            prod = np.abs(as_ * x_host[ja])
+            scale = np.add.reduceat(np.concatenate([prod, [0.0]]), np.minimum(irp[:-1].astype(np.int64), nnz))
+            scale = np.where(np.diff(irp.astype(np.int64)) > 0, scale, 0.0)
+            del prod
+            b_csr = synth.algorithmic_bytes_csr(nnz, M, M)
+            b_ell = M * K * 12 + M * 8 + M * 8
+            blk["algorithmic_bytes"] = {"B_csr = B_ell_rl": b_csr, "B_ell (all slots)": b_ell}
+            x = torch.from_numpy(x_host).cuda()
+            y = torch.full((M,), float("nan"), dtype=torch.float64, device="cuda")
+
+            def run(label, launcher, mat, nbytes, variant=-1, rl=None, bitwise=False):
+                if variant >= 0:
+                    api.set_variant(launcher, variant)
+                if rl is not None:
+                    api.lib.spmvHipSetEllRowLens(1 if rl else 0)
+                y.fill_(float("nan"))
+                res, kms = time_launcher(api, torch, mat, launcher, x, y, steps, warmup)
+                k_avg, k_var = avg_var(api, kms)
+                yg = y.cpu().numpy()
+                d = np.abs(yg - y_ref)
+                nz_rows = scale > 0
+                par = {"rows_checked": M, "nan": bool(np.isnan(yg).any()), "max_abs_diff": float(np.nanmax(d)),
+                       "max_diff_over_sum_abs_ax": float(np.max(d[nz_rows] / scale[nz_rows])) if nz_rows.any() else 0.0}
+                if bitwise:
+                    par["bit_identical"] = bool(np.array_equal(yg, y_ref + 0.0))
+                par["ok"] = bool(not par["nan"] and par["max_abs_diff"] <= GATE and par.get("bit_identical", True))
+                r = {"kernel": label, "launcher": launcher, "variant": variant if variant >= 0 else None, "row_lens_early_exit": rl,
+                     "kernel_ms_avg": k_avg, "kernel_ms_var": k_var, "gflops": 2.0 * nnz / (k_avg * 1e-3) * 1e-9,
+                     "bytes_convention": "B_csr" if nbytes == b_csr else "B_ell", "hbm_gbps": nbytes / (k_avg * 1e-3) * 1e-9,
+                     "hbm_frac": nbytes / (k_avg * 1e-3) / HBM_PEAK, "parity": par}
+                if launcher == "hipSpMVRowsCSR" and variant == 2:
+                    nm = api.lib.spmvHipAutoChoiceRows(C.byref(mat.handle), None)
+                    r["resolved_to"] = nm.decode() if nm else None
+                if launcher == "hipSpMVWarpPerRowCSR" and variant == 2:
+                    nm = api.lib.spmvHipAutoChoice(C.byref(mat.handle), None)
+                    r["resolved_to"] = nm.decode() if nm else None
+                blk["runs"].append(r)
+                log(f"{spec['name']} {label}: kernel {k_avg:.4f} ms  {r['gflops']:.0f} GFLOP/s  {100 * r['hbm_frac']:.1f}% ({r['bytes_convention']})  "
+                    f"parity ok={par['ok']}" + (f"  -> {r['resolved_to']}" if r.get("resolved_to") else ""))
+                if not par["ok"]:
+                    raise SystemExit(f"PARITY FAILURE on {spec['name']} [{label}]: {par}")
+
+            t4 = time.perf_counter()
+            dm = api.DeviceMatrix()
+            if api.lib.spMatCpyCSR(csr, C.byref(dm.handle)):
+                raise RuntimeError("spMatCpyCSR failed")
+            dm.rows = M
+            dms.append(dm)
+            blk["spMatCpyCSR_s"] = time.perf_counter() - t4
+            run("CSR thread per row, as named by the reference (hipSpMVRowsCSR, default: fastest serial-order kernel)", "hipSpMVRowsCSR", dm, b_csr, 2, bitwise=True)
+            run("CSR thread per row, LDS-stream kernel", "hipSpMVRowsCSR", dm, b_csr, 1, bitwise=True)
+            run("CSR wavefront per row, as named by the reference (hipSpMVWarpPerRowCSR, default: fastest reduction-order kernel)", "hipSpMVWarpPerRowCSR", dm, b_csr, 2)
+            run("CSR wavefront per row, LDS-stream kernel + LDS segmented reduction", "hipSpMVWarpPerRowCSR", dm, b_csr, 1)
+            run("CSR one wavefront per row (the reference kernel's intent)", "hipSpMVWarpPerRowCSR", dm, b_csr, 0)
+            run("CSR two-phase", "hipSpMVTilesCSR", dm, b_csr)
+            run("CSR stripes", "hipSpMVStripesCSR", dm, b_csr)
+            run("SELL-C-sigma", "hipSpMVRowsSELL", dm, b_csr)
+            set_rows_variant(api, 1)
+            api.set_variant("hipSpMVWarpPerRowCSR", 1)
+            dm.free()
+            dms.clear()
+            # ELL: the loader's row-major matrix, and its ellTranspose()d form for the coalesced thread-per-row kernel
+            t5 = time.perf_counter()
+            ell_t = H.ellTranspose(ell)
+            blk["ellTranspose_s"] = time.perf_counter() - t5
+            if not ell_t:
+                raise RuntimeError("ellTranspose failed")
+            de_t = api.DeviceMatrix()
+            if api.lib.spMatCpyELL(ell_t, C.byref(de_t.handle)):
+                raise RuntimeError("spMatCpyELL (transposed) failed")
+            dms.append(de_t)
+            for rl in (True, False):
+                run("ELL transposed+pitched, thread per row", "hipSpMVRowsELL", de_t, b_csr if rl else b_ell, rl=rl, bitwise=True)
+            de_t.free()
+            dms.clear()
+            de = api.DeviceMatrix()
+            if api.lib.spMatCpyELL(ell, C.byref(de.handle)):
+                raise RuntimeError("spMatCpyELL failed")
+            dms.append(de)
+            for rl in (True, False):
+                run("ELL row-major, thread per row", "hipSpMVRowsELLNNTransposed", de, b_csr if rl else b_ell, rl=rl, bitwise=True)
+                run("ELL row-major, lanes per row (wavefront-per-row family)", "hipSpMVWarpsPerRowELLNTrasposed", de, b_csr if rl else b_ell, rl=rl)
+            de.free()
+            dms.clear()
+            api.lib.spmvHipSetEllRowLens(1)
+            best = min(blk["runs"], key=lambda r: r["kernel_ms_avg"])
+            blk["fastest"] = {"kernel": best["kernel"], "kernel_ms_avg": best["kernel_ms_avg"], "gflops": best["gflops"], "hbm_frac_B_csr": b_csr / (best["kernel_ms_avg"] * 1e-3) / HBM_PEAK}
+            # the reference's OpenMP row-parallel kernels on the loader's own host matrices (static schedule, all entitled cores)
+            if not args.no_cpu_baseline:
+                cfg = ref_CONFIG()
+                cfg.gridRows = cfg.gridCols = 8
+                cfg.threadNum = int((cpu.refMaxThreads if cpu_kind == "reference" else ora.oracleMaxThreads)())
+                cfg.chunkDistrbFunc = noop() if noop is not None else None
+                y_cpu = np.empty(M)
+                base = {"kind": cpu_kind, "cores": int(cfg.threadNum), "unit": "GFLOP/s", "schedule": "static", **effective_cpus()}
+                for label, fn, mat in (("spmvRowsBasicCSR", cpu.spmvRowsBasicCSR, csr), ("spmvRowsBasicELL (row lengths)", cpu.spmvRowsBasicELL, ell)):
+                    ts = []
+                    for _ in range(4):
+                        y_cpu[:] = np.nan
+                        t0 = time.perf_counter()
+                        rc = fn(mat, x_host.ctypes.data_as(vp), C.byref(cfg), y_cpu.ctypes.data_as(vp))
+                        ts.append(time.perf_counter() - t0)
+                        if rc or not np.all(np.abs(y_cpu - y_ref) <= GATE):
+                            raise SystemExit(f"CPU baseline {label} failed the gate on {spec['name']}")
+                    base[label] = {"gflops": 2.0 * nnz / (sum(ts[1:]) / 3) * 1e-9, "pass_seconds_avg": sum(ts[1:]) / 3}
+                blk["cpu_baseline"] = base
+                log(f"{spec['name']} CPU ({cpu_kind}, {cfg.threadNum} threads): CSR {base['spmvRowsBasicCSR']['gflops']:.2f}  ELL {base['spmvRowsBasicELL (row lengths)']['gflops']:.2f} GFLOP/s")
+        finally:
+            for dmx in dms:
+                dmx.free()
+            for ptr in (csr, ell, ell_t):
+                if ptr:
+                    H.freeSpmat(ptr)
+            if os.path.exists(path):
+                os.remove(path)
+            torch.cuda.empty_cache()
+        out["matrices"].append(blk)
     return out
 
 
@@ -572,6 +934,10 @@ _REAL_STDOUT = None
 
 def run_single(args, api, synth, torch, w):
     steps, warmup = args.steps, args.warmup
+    if args.only_structured:
+        emit({"metric": "spmv_gflops", "unit": "GFLOP/s", "n_gpus": 1, "steps": steps, "warmup": warmup, "dtype": "f64", "data": "synthetic",
+              "extra_structured": measure_structured(api, synth, torch, args, min(steps, 10), min(warmup, 2), only=args.only_structured)})
+        return
     res = measure_block(api, synth, torch, w, args.launcher, steps, warmup,
                         cpu_rows=0 if args.no_cpu_baseline else args.cpu_sample_nnz)
     extra = {}
@@ -583,11 +949,16 @@ def run_single(args, api, synth, torch, w):
             if args.scale != 1.0:
                 we = synth.scaled(we, args.scale)
             # config 2 is quoted on a thread-per-row kernel: pick among the one-lane-per-row launchers only (all are timed)
+            # -- hipSpMVRowsCSR in its library default (variant 2: the fastest SERIAL-ORDER kernel, bit-identical to one thread
+            # walking the row) and SELL
             cands = THREAD_PER_ROW if key.startswith("c2") else None
+            set_rows_variant(api, 2 if key.startswith("c2") else 1)
             # the configuration the roofline target is quoted on also gets the CPU baseline, on the WHOLE matrix
             extra[key] = measure_block(api, synth, torch, we, args.launcher, steps, warmup, cands,
                                        cpu_rows=(1 << 62) if key == "c3" and not args.no_cpu_baseline else 0)
+            set_rows_variant(api, 1)
         extra["c4"] = measure_c4(api, synth, torch, args, min(steps, 10), min(warmup, 2))
+        extra["structured"] = measure_structured(api, synth, torch, args, min(steps, 10), min(warmup, 2))
     traffic, traffic_note = pmc_traffic(api, res["workload"]["workload"], res["launcher"])
     line = {
         "metric": "spmv_gflops", "value": res["gflops"], "unit": "GFLOP/s", "n_gpus": 1, "steps": steps,
@@ -596,6 +967,7 @@ def run_single(args, api, synth, torch, w):
         "config": {"workload": res["workload"]["workload"], **{k: v for k, v in res["workload"].items() if k != "workload"},
                    "kernel": res["launcher"], "auto_candidates_ms": res["auto_candidates_ms"],
                    "library_auto_choice": res.get("library_auto_choice"),
+                   "library_serial_order_choice": res.get("library_serial_order_choice"),
                    "parallelism": "1 GPU", "libspmvhip_sha256": lib_sha256(api)},
         "hbm_gbps": res["hbm_gbps"], "hbm_roofline_frac": res["hbm_frac"],
         "roofline": {"bound": "hbm", "achieved": res["hbm_gbps"], "peak": HBM_PEAK * 1e-9, "unit": "GB/s",
@@ -612,7 +984,7 @@ def run_single(args, api, synth, torch, w):
         line["cpu_baseline"] = res["cpu_baseline"]
     if "c3" in extra:
         line["headline_c3"] = extra["c3"]
-    for k in ("c3b", "c2", "c4"):
+    for k in ("c3b", "c2", "c4", "structured"):
         if k in extra:
             line["extra_" + k] = extra[k]
     emit(line)
@@ -965,6 +1337,9 @@ def main():
         # OpenMP library is loaded (ranks of a multi-GPU job share the host cores and are not bound)
         os.environ.setdefault("OMP_PROC_BIND", "close")
         os.environ.setdefault("OMP_PLACES", "cores")
+        # one OpenMP thread per CPU this process is ENTITLED to (affinity mask capped by the cgroup quota): 128 threads
+        # on a 16-CPU share would time the scheduler, not the loop
+        os.environ.setdefault("OMP_NUM_THREADS", str(effective_cpus()["effective_cpus"]))
     import torch                      # BEFORE the HIP library: one HIP runtime per process (see api.py)
     import torch.distributed as dist
     rank = int(os.environ.get("RANK", "0"))
@@ -995,6 +1370,7 @@ def main():
     # (variant 1), not the default variant 2 that picks among them -- what that default picks is reported per block as
     # `library_auto_choice`
     api.set_variant("hipSpMVWarpPerRowCSR", 1)
+    set_rows_variant(api, 1)
     if args.variant >= 0 and args.launcher != "auto":
         api.set_variant(args.launcher, args.variant)
     w = synth.WORKLOADS[args.workload]

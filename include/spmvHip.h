@@ -174,6 +174,10 @@ int spmvHipStripesInfo(spmat* dMat, spmvStripesInfo* info);   /* zeros when the 
  * ms in the order above (0 = not eligible / not tried).  Arrival-order sums when a format kernel wins. */
 SPMV_HIP hipSpMVAutoCSR;
 const char* spmvHipAutoChoice(spmat* dMat, double* msPerCandidate);
+/* The same report for the selection hipSpMVRowsCSR (variant 2) makes among the SERIAL-ORDER kernels: "hipSpMVRowsCSR" (the
+ * LDS-stream kernel, one thread per row), "hipSpMVTilesCSR(deterministic)", "hipSpMVStripesCSR(deterministic)"; the three
+ * times in that order.  Whichever is chosen, y is the bits of sgemvSerial. */
+const char* spmvHipAutoChoiceRows(spmat* dMat, double* msPerCandidate);
 
 /* SELL-C-sigma (C = 64 rows per slice = one wavefront, rows sorted by length inside 16 Ki-row
  * windows, column-major inside a slice) built on the device from an uploaded CSR handle at the
@@ -192,12 +196,23 @@ int spmvHipEnqueueCSR(spmat* dMat, int warpPerRow, double* dX, double* dY, void*
 /* The same for the launcher hipSpMVAutoCSR / hipSpMVWarpPerRowCSR (variant 2) chose for this handle; the FIRST call for a
  * handle measures the candidates on `stream` and synchronises it (later calls only enqueue). */
 int spmvHipEnqueueAuto(spmat* dMat, double* dX, double* dY, void* stream);
+/* ... and for the launcher hipSpMVRowsCSR (variant 2) chose: serial-order sums, y bit-identical to sgemvSerial. */
+int spmvHipEnqueueAutoRows(spmat* dMat, double* dX, double* dY, void* stream);
 
 /* Kernel variants behind each launcher (for A/B measurement; default = best):
  *   hipSpMVRowsCSR        0 = one thread walks its row in global memory: the plain restatement of
  *                             cudaSpMVRowsCSR (uncoalesced; 5-6x slower, profiles/r01_variants.md)
- *                         1 = (default) LDS-stream kernel: coalesced span load, products parked in LDS, one
+ *                         1 = LDS-stream kernel: coalesced span load, products parked in LDS, one
  *                             thread sums its row in ascending-j order (bit-identical to the serial oracle)
+ *                         2 = (default) the fastest of this library's SERIAL-ORDER kernels for THIS matrix -- variant 1
+ *                             and the deterministic forms of the two-phase and the stripes kernel (spmvTilesOpts /
+ *                             spmvStripesOpts .deterministic) -- chosen by measurement at the first call for a handle,
+ *                             like variant 2 of hipSpMVWarpPerRowCSR below (same first-call cost, same +12 B/nnz for
+ *                             the winner's copy of the matrix; matrices below 2^18 entries go straight to variant 1).
+ *                             Every candidate adds a row's products in ascending column order with the product rounded
+ *                             first, so y is the bits of sgemvSerial whichever is chosen (for rows whose columns ascend,
+ *                             which the reference's loader guarantees, src/lib/parser.c:195-202).  Reached by the
+ *                             reference's names SpmvCUDA_CSRFuncs[0], CUDA_CSR_ROWS, spmvHipRowsCSR.
  *   hipSpMVWarpPerRowCSR  0 = one wavefront per row, __shfl_down tree (the reference kernel's intent, for
  *                             every row)
  *                         1 = LDS-stream kernel with the LDS segmented reduction for short rows and
@@ -213,6 +228,11 @@ int spmvHipEnqueueAuto(spmat* dMat, double* dX, double* dY, void* stream);
  *                             the reference's names reach: SpmvCUDA_CSRFuncs[SpmvCUDA_CSRFuncs_WarpPerRowIdx],
  *                             CUDA_CSR_ROWS_WARP, spmvHipWarpPerRowCSR (src/include/SpMV.h:130-134).  A caller that
  *                             wants the one-kernel behaviour of round 1/2 sets variant 1 (CLI: SPMV_VARIANT=1).
+ *   hipSpMVRowsELLNNTransposed  0 = one thread walks its row of the row-major matrix in global memory: the plain
+ *                             restatement of cudaSpMVRowsELLNNTransposed (a lane's loads lie a pitch apart: uncoalesced by
+ *                             construction, the reference's slowest kernel); also what runs when CONFIG.blockSize is given
+ *                         1 = (default) the same sums -- one thread adds its row's cells in ascending slot order, bit for
+ *                             bit -- fed from a coalesced span parked in LDS (rows of up to 2048 slots; longer: variant 0)
  * Returns EXIT_FAILURE for an unknown (launcher, variant). */
 int spmvHipSetVariant(const char* launcher, int variant);
 /* Use the RL array for ELL early exit (1, default when RL was uploaded) or walk
@@ -257,9 +277,9 @@ int spmvHipShardCSR(spmat* host, int nDev, void** shardHandle);
 /* ... with every device's rows cut into `groups` consecutive row groups (0 = automatic: 2 when nDev > 1): the
  * all-gather of group g runs on its own stream while group g+1 is computed. */
 int spmvHipShardCSRGroups(spmat* host, int nDev, int groups, void** shardHandle);
-/* mode 0: the kernel of hipSpMVRowsCSR (serial order: y bit-identical to the 1-GPU result); mode != 0: that of
- * hipSpMVWarpPerRowCSR (variant 2: the fastest reduction-order kernel per block, chosen by an untimed pass at the first
- * call).  kernelSec = kernels of all row groups, slowest device; gatherSec = what the exchange adds after overlap. */
+/* mode 0: the kernel hipSpMVRowsCSR runs (variant 2: the fastest serial-order kernel per block; y bit-identical to the
+ * 1-GPU result and to sgemvSerial); mode != 0: that of hipSpMVWarpPerRowCSR (variant 2: the fastest reduction-order kernel
+ * per block).  Either selection is made by an untimed pass at the first call with that mode.  kernelSec = kernels of all row groups, slowest device; gatherSec = what the exchange adds after overlap. */
 int spmvHipSpMVSharded(void* shardHandle, const double* hX, int mode, double* hY,
                        double* kernelSec, double* gatherSec);
 int spmvHipShardFree(void* shardHandle);

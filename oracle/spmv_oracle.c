@@ -269,3 +269,48 @@ void oracleFirstTouchCsr(ulong M, const ulong* IRP, const ulong* jaSrc, const do
 /* what libgomp actually bound: number of places and the binding policy (0 false, 1 true, 2 master, 3 close, 4 spread) */
 int oracleOmpPlaces(void) { return omp_get_num_places(); }
 int oracleOmpProcBind(void) { return (int)omp_get_proc_bind(); }
+
+/* ---- sanity figures beside the CPU baseline (bench.py) --------------------------------------
+ * How many threads a parallel region REALLY gets (affinity masks, cgroup quotas and OMP_NUM_THREADS all have a say),
+ * how many distinct CPUs they sit on, and what the same static row partition streams when no x is gathered: the row
+ * sums of AS (8 B per entry + 16 B per row).  A CSR SpMV that is far below this figure is bound by its gather, one that
+ * is near it by memory bandwidth; a stream figure far below the machine's says the threads share too few cores. */
+int oracleThreadsInRegion(void) {
+    int n = 0;
+    #pragma omp parallel
+    {
+        #pragma omp single
+        n = omp_get_num_threads();
+    }
+    return n;
+}
+#ifndef _GNU_SOURCE
+#define _GNU_SOURCE
+#endif
+#include <sched.h>
+extern int sched_getcpu(void);
+int oracleDistinctCpusInRegion(void) {
+    enum { MAXCPU = 4096 };
+    static unsigned char seen[MAXCPU];
+    for (int i = 0; i < MAXCPU; ++i) seen[i] = 0;
+    #pragma omp parallel
+    {
+        volatile double spin = 0;                      /* long enough for the scheduler to spread the threads */
+        for (int i = 0; i < 2000000; ++i) spin += i * 1e-9;
+        const int c = sched_getcpu();
+        if (c >= 0 && c < MAXCPU) seen[c] = 1;
+    }
+    int n = 0;
+    for (int i = 0; i < MAXCPU; ++i) n += seen[i];
+    return n;
+}
+double oracleRowSumSeconds(ulong M, const ulong* IRP, const double* AS, double* y) {
+    const double t0 = omp_get_wtime();
+    #pragma omp parallel for schedule(static)
+    for (ulong r = 0; r < M; r++) {
+        double acc = 0;
+        for (ulong j = IRP[r]; j < IRP[r + 1]; j++) acc += AS[j];
+        y[r] = acc;
+    }
+    return omp_get_wtime() - t0;
+}

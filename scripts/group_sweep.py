@@ -28,5 +28,5 @@ for G in [int(a) for a in sys.argv[2:]]:
     ms = C.c_float(); api.lib.spmvHipEventElapsedMs(e0, e1, C.byref(ms))
     nnz = int(irp[-1])
     alg = synth.algorithmic_bytes_csr(nnz, w.N, w.N)
-    print(f"{w.name} G={G} NTSTORE={os.environ.get('SPMV_PB_NTSTORE','auto')}: {ms.value / 10:.4f} ms  {alg / (ms.value / 10 * 1e-3) / 8e12 * 100:.1f} % of 8 TB/s", flush=True)
+    print(f"{w.name} G={G}: {ms.value / 10:.4f} ms  {alg / (ms.value / 10 * 1e-3) / 8e12 * 100:.1f} % of 8 TB/s", flush=True)
     for dm in dms: dm.free()

@@ -23,4 +23,4 @@ for g in range(G):
             api.spmv(launcher, dm, dx, dy); ts.append(api.lib.spmvHipLastKernelSeconds())
         tot[launcher] = tot.get(launcher, 0) + sum(ts) / len(ts)
     dm.free(); dy.free()
-print(f"N={N} G={G} rows/rank={plan.rows(0)[1]} ROWS={os.environ.get('SPMV_PB_ROWS','auto')}: " + "  ".join(f"{k} {v*1e3:.3f} ms" for k, v in tot.items()))
+print(f"N={N} G={G} rows/rank={plan.rows(0)[1]}: " + "  ".join(f"{k} {v*1e3:.3f} ms" for k, v in tot.items()))

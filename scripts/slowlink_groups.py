@@ -54,5 +54,5 @@ for G in [int(a) for a in sys.argv[2:]] or [1, 2, 4]:
     api.lib.spmvHipDeviceSynchronize()
     ok = all(api.lib.spmvHipTilesPushFailed(h) == 0 for h in hs) and np.array_equal(host.numpy(), dy.down())
     print(f"{w.name} y = {w.N * 8 / 1e6:.0f} MB to pinned host, G = {G} row groups ({sum(nbs)} bins): kernels alone {t0:.3f} ms; fused store {t1:.3f} ms; "
-          f"copy-engine push behind each group {t3:.3f} ms; push kernel {t2:.3f} ms (complete and identical: {ok}) TAPER={os.environ.get('SPMV_PB_TAPER', '0')}", flush=True)
+          f"copy-engine push behind each group {t3:.3f} ms; push kernel {t2:.3f} ms (complete and identical: {ok})", flush=True)
     for d in dms: d.free()

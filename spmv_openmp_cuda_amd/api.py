@@ -63,6 +63,8 @@ _sigs = {
     "spmvHipStripesShape": ([C.POINTER(spmat), C.POINTER(C.c_uint), C.POINTER(C.c_uint), C.POINTER(_i), C.POINTER(C.c_double)], _i),
     "spmvHipEnqueueCSR": ([C.POINTER(spmat), _i, _vp, _vp, _vp], _i),
     "spmvHipEnqueueAuto": ([C.POINTER(spmat), _vp, _vp, _vp], _i),
+    "spmvHipEnqueueAutoRows": ([C.POINTER(spmat), _vp, _vp, _vp], _i),
+    "spmvHipAutoChoiceRows": ([C.POINTER(spmat), C.POINTER(C.c_double)], C.c_char_p),
     "spmvHipBuildStripesOpt": ([C.POINTER(spmat), _vp], _i), "spmvHipStripesInfo": ([C.POINTER(spmat), _vp], _i),
     "spmvHipShardCSR": ([C.POINTER(spmat), _i, C.POINTER(_vp)], _i),
     "spmvHipShardCSRGroups": ([C.POINTER(spmat), _i, _i, C.POINTER(_vp)], _i),
@@ -147,6 +149,9 @@ _hsigs = {
     "spmvSynthPrefix": ([_vp, _u64, _vp], _u64),
     "spmvSynthMakeX": ([_u64, _u64, _vp], None),
     "spmvSynthPerm": ([_u64, _u64, _u64], _u64),
+    "spmvSynthWriteMtx": ([C.c_char_p, _i, C.c_ulong, C.c_ulong, C.c_ulong, _u64, C.POINTER(C.c_ulong), C.POINTER(C.c_ulong),
+                           C.POINTER(C.c_ulong)], _i),
+    "spmvSynthStructuredValue": ([_u64, C.c_ulong, C.c_ulong], C.c_double),
 }
 for _name, (_args, _res) in _hsigs.items():
     _f = getattr(hostlib, _name)

@@ -20,9 +20,11 @@ struct State {
     int         dev = 0;
     hipStream_t stream = nullptr;
     bool        sync = true;
-    int         variantRowsCSR = 1;     // 0 scalar restatement, 1 LDS-stream kernel (sequential row sums)
+    int         variantRowsCSR = 2;     // 0 scalar restatement, 1 LDS-stream kernel (sequential row sums), 2 the fastest serial-order
+                                        // kernel for the matrix (LDS-stream / deterministic two-phase / deterministic stripes)
     int         variantWarpCSR = 2;     // 0 wavefront-per-row restatement, 1 LDS-stream kernel (LDS segmented reduction), 2 the fastest
                                         // reduction-order kernel for the matrix (LDS-stream / two-phase / stripes), measured at first use
+    int         variantEllRowMajor = 1; // hipSpMVRowsELLNNTransposed: 0 a thread walks its row in global memory, 1 LDS-stream kernel, same sums
     bool        ellRowLens = true;
     double      lastSeconds = 0;
     spmvDim3    lastGrid{0, 0, 0}, lastBlock{0, 0, 0};
@@ -97,9 +99,9 @@ void freeDesc(DevMat* d) {
         (void)hipFree(d->IRP); (void)hipFree(d->JA); (void)hipFree(d->AS); (void)hipFree(d->RL);
     }
     (void)hipFree(d->blkInfo); (void)hipFree(d->blkBase);
-    freeTiles(d->tiles);
+    freeTiles(d->tiles); freeTiles(d->tilesAlt);
     freeSell(d->sell);
-    freeStripes(d->stripes);
+    freeStripes(d->stripes); freeStripes(d->stripesAlt);
     d->magic = 0;
     delete d;
 }
@@ -207,6 +209,20 @@ static void launchStream2(DevMat* d, double* x, double* y) {
                            d->nBlk2, d->nLong2, d->blkInfo, d->blkBase, static_cast<const uint64_t*>(d->IRP), d->JA, d->AS, x, y);
 }
 
+// row-major ELL through the LDS-stream kernel (a row must fit a block): seq = one thread sums a row in ascending slots
+static int launchEllStream(DevMat* d, bool rl, bool seq, double* x, double* y, const char* who) {
+    const uint32_t rowsPerBlk = std::min<uint32_t>((uint32_t)(STREAM_NNZ / d->pitch), WG_THREADS);
+    const uint64_t nBlk = (d->M + rowsPerBlk - 1) / rowsPerBlk;
+    const dim3 grid = grid2d(nBlk, WG_THREADS), block(WG_THREADS);
+    Launch L(grid, block);
+#define ELL_STREAM(RLV, SEQV) hipLaunchKernelGGL((ell_stream_kernel<RLV, SEQV>), grid, block, 0, S.stream, (uint32_t)d->M, (uint32_t)d->K, \
+                                                 (uint32_t)d->pitch, rowsPerBlk, nBlk, d->JA, d->AS, d->RL, x, y)
+    if (rl) { if (seq) ELL_STREAM(true, true); else ELL_STREAM(true, false); }
+    else    { if (seq) ELL_STREAM(false, true); else ELL_STREAM(false, false); }
+#undef ELL_STREAM
+    return L.finish(who);
+}
+
 template <int G>
 static void launchEllGroup(DevMat* d, bool rl, dim3 grid, dim3 block, double* x, double* y) {
     if (rl) hipLaunchKernelGGL((ell_rowmajor_group<true, G>), grid, block, 0, S.stream, (uint32_t)d->M, (uint32_t)d->K, d->pitch, d->JA, d->AS, d->RL, x, y);
@@ -265,7 +281,7 @@ static int ellUpload(spmat* m, spmat* dst, bool transposed) {
     int rc;
     const ulong colLimit = transposed ? (cols ? cols - 1 : 0xFFFFFFFFul) : (m->N ? m->N - 1 : 0);
     if (transposed) rc = uploadPitched(d, m->JA, m->AS, slots, rows, (rows + 63) / 64 * 64, colLimit);
-    else            rc = uploadPitched(d, m->JA, m->AS, rows, slots, (slots + 15) / 16 * 16, colLimit);
+    else            rc = uploadPitched(d, m->JA, m->AS, rows, slots, (slots + 1) / 2 * 2, colLimit);   // (rows stay 16-B aligned; a wider pitch is only padding to stream)
     if (!rc && m->RL) rc = narrowUpload<uint32_t>(&d->RL, m->RL, rows, slots, "RL");
     if (rc) { freeDesc(d); return EXIT_FAILURE; }
     publish(dst, d, m->M, m->N, m->NZ, m->MAX_ROW_NZ);
@@ -381,8 +397,9 @@ int spmvHipDeviceSynchronize(void) { HIP_TRY(hipDeviceSynchronize()); return EXI
 
 int spmvHipSetVariant(const char* launcher, int variant) {
     if (!launcher) return EXIT_FAILURE;
-    if (!strcmp(launcher, "hipSpMVRowsCSR") && variant >= 0 && variant <= 1) { S.variantRowsCSR = variant; return EXIT_SUCCESS; }
+    if (!strcmp(launcher, "hipSpMVRowsCSR") && variant >= 0 && variant <= 2) { S.variantRowsCSR = variant; return EXIT_SUCCESS; }
     if (!strcmp(launcher, "hipSpMVWarpPerRowCSR") && variant >= 0 && variant <= 2) { S.variantWarpCSR = variant; return EXIT_SUCCESS; }
+    if (!strcmp(launcher, "hipSpMVRowsELLNNTransposed") && variant >= 0 && variant <= 1) { S.variantEllRowMajor = variant; return EXIT_SUCCESS; }
     ERR("spmvHipSetVariant: unknown (%s, %d)", launcher, variant);
     return EXIT_FAILURE;
 }
@@ -492,7 +509,7 @@ int spmvHipCsrToEll(spmat* dCsr, int transposed, spmat* dEll) {
     DevMat* d = new DevMat;
     d->kind = transposed ? Kind::ELL_COLMAJOR : Kind::ELL_ROWMAJOR;
     d->M = rows; d->N = c->N; d->NZ = c->NZ; d->K = K;
-    d->pitch = transposed ? (rows + 63) / 64 * 64 : (K + 15) / 16 * 16;
+    d->pitch = transposed ? (rows + 63) / 64 * 64 : (K + 1) / 2 * 2;
     const size_t cells = std::max<size_t>((transposed ? K : rows) * d->pitch, 1);
     {   // ELL size guard.  The reference's loader refuses an ELL copy whose 2*M*maxRow padded cells exceed a fixed host
         // budget (src/lib/parser.c:223-232, config.h:69-70: 6*2^27 cells); on the device the budget is what the GPU has
@@ -553,42 +570,81 @@ int spmvHipEnqueueCSR(spmat* dMat, int warpPerRow, double* dX, double* dY, void*
     return EXIT_SUCCESS;
 }
 
+// ---- CSR launchers --------------------------------------------------------------------------------------------
+// the LDS-stream kernel: SEQ = one thread sums its row in ascending j (variant 1 of hipSpMVRowsCSR), otherwise the LDS
+// segmented reduction (variant 1 of hipSpMVWarpPerRowCSR); candidate 0 of the two selections below
+static int streamCSR(spmat* dMat, double* dX, double* dY, bool seq) {
+    const char* who = seq ? "hipSpMVRowsCSR" : "hipSpMVWarpPerRowCSR";
+    DevMat* d = descOf(dMat, who);
+    if (!d) return EXIT_FAILURE;
+    if (d->kind != Kind::CSR) { ERR("%s: handle is not CSR", who); return EXIT_FAILURE; }
+    if (d->M == 0) return nothingToLaunch(d, nullptr);
+    Launch L(grid2d(d->nBlk2, WG_THREADS), dim3(WG_THREADS));
+    if (seq) launchStream2<true>(d, dX, dY); else launchStream2<false>(d, dX, dY);
+    return L.finish(who);
+}
+static int streamSerial(spmat* m, double* x, CONFIG, double* y)  { return streamCSR(m, x, y, true); }
+static int streamReduce(spmat* m, double* x, CONFIG, double* y)  { return streamCSR(m, x, y, false); }
+
+// the two-phase / stripes launchers on the given FORM of their format (built at the first call)
+static int tilesForm(spmat* dMat, double* dX, double* dY, bool det, const char* who) {
+    DevMat* d = descOf(dMat, who);
+    if (!d) return EXIT_FAILURE;
+    if (d->kind != Kind::CSR) { ERR("%s: handle is not CSR", who); return EXIT_FAILURE; }
+    if (d->M == 0 || d->NZ == 0) return nothingToLaunch(d, dY);         // nothing to slice: y = 0
+    useTiles(d, det);
+    if (!d->tiles) {
+        const spmvTilesOpts o{0, 0, -1, 0, 1};
+        if (buildTiles(d, det ? &o : nullptr)) return EXIT_FAILURE;
+    }
+    uint32_t bins = 0, rowsPerBin = 0;
+    tilesShape(d, &bins, &rowsPerBin);
+    Launch L(grid2d((uint64_t)((bins + 7) / 8) * 8, det ? 256 : 1024), dim3(det ? 256 : 1024));   // phase 2's shape (phase 1: one workgroup per slice piece)
+    if (enqueueTiles(d, dX, dY, S.stream)) { ERR("%s: launch failed", who); return EXIT_FAILURE; }
+    return L.finish(who);
+}
+static int stripesForm(spmat* dMat, double* dX, double* dY, bool det, const char* who) {
+    DevMat* d = descOf(dMat, who);
+    if (!d) return EXIT_FAILURE;
+    if (d->kind != Kind::CSR) { ERR("%s: handle is not CSR", who); return EXIT_FAILURE; }
+    if (d->M == 0 || d->NZ == 0) return nothingToLaunch(d, dY);         // nothing to sweep: y = 0
+    useStripes(d, det);
+    if (!d->stripes) {
+        const spmvStripesOpts o{0, 0, -1, -1, 1};
+        if (buildStripes(d, det ? &o : nullptr)) return EXIT_FAILURE;
+    }
+    Launch L(dim3(1), dim3(1));
+    dim3 grid, block;
+    if (enqueueStripes(d, dX, dY, S.stream, &grid, &block)) { ERR("%s: launch failed", who); return EXIT_FAILURE; }
+    L.shape(grid, block);                            // the persistent grid that ran: min(bins, CUs) workgroups of 256 threads
+    return L.finish(who);
+}
+static int tilesArrival(spmat* m, double* x, CONFIG, double* y)   { return tilesForm(m, x, y, false, "hipSpMVTilesCSR"); }
+static int tilesSerial(spmat* m, double* x, CONFIG, double* y)    { return tilesForm(m, x, y, true, "hipSpMVTilesCSR (deterministic)"); }
+static int stripesArrival(spmat* m, double* x, CONFIG, double* y) { return stripesForm(m, x, y, false, "hipSpMVStripesCSR"); }
+static int stripesSerial(spmat* m, double* x, CONFIG, double* y)  { return stripesForm(m, x, y, true, "hipSpMVStripesCSR (deterministic)"); }
+
+static int autoRun(spmat* dMat, double* dX, CONFIG cfg, double* dY, int serial, const char* who);
+
 int hipSpMVRowsCSR(spmat* dMat, double* dX, CONFIG cfg, double* dY) {
+    if (S.variantRowsCSR == 2) return autoRun(dMat, dX, cfg, dY, 1, "hipSpMVRowsCSR");
+    if (S.variantRowsCSR == 1) return streamSerial(dMat, dX, cfg, dY);
     DevMat* d = descOf(dMat, "hipSpMVRowsCSR");
     if (!d) return EXIT_FAILURE;
     if (d->kind != Kind::CSR) { ERR("hipSpMVRowsCSR: handle is not CSR"); return EXIT_FAILURE; }
     if (d->M == 0) return nothingToLaunch(d, nullptr);
-    if (S.variantRowsCSR == 0) {
-        const unsigned bt = blockThreads(cfg, BLOCKS_1D, 1024);
-        const dim3 grid = grid2d((d->M + bt - 1) / bt, bt), block(bt);
-        Launch L(grid, block);
-        const uint32_t M = (uint32_t)d->M;
-        if (d->irpBytes == 4) hipLaunchKernelGGL((csr_scalar_kernel<uint32_t>), grid, block, 0, S.stream, M, static_cast<const uint32_t*>(d->IRP), d->JA, d->AS, dX, dY);
-        else                  hipLaunchKernelGGL((csr_scalar_kernel<uint64_t>), grid, block, 0, S.stream, M, static_cast<const uint64_t*>(d->IRP), d->JA, d->AS, dX, dY);
-        return L.finish("hipSpMVRowsCSR");
-    }
-    Launch L(grid2d(d->nBlk2, WG_THREADS), dim3(WG_THREADS));
-    launchStream2<true>(d, dX, dY);
+    const unsigned bt = blockThreads(cfg, BLOCKS_1D, 1024);
+    const dim3 grid = grid2d((d->M + bt - 1) / bt, bt), block(bt);
+    Launch L(grid, block);
+    const uint32_t M = (uint32_t)d->M;
+    if (d->irpBytes == 4) hipLaunchKernelGGL((csr_scalar_kernel<uint32_t>), grid, block, 0, S.stream, M, static_cast<const uint32_t*>(d->IRP), d->JA, d->AS, dX, dY);
+    else                  hipLaunchKernelGGL((csr_scalar_kernel<uint64_t>), grid, block, 0, S.stream, M, static_cast<const uint64_t*>(d->IRP), d->JA, d->AS, dX, dY);
     return L.finish("hipSpMVRowsCSR");
 }
 
-// the LDS-stream kernel with the LDS segmented reduction (variant 1 of hipSpMVWarpPerRowCSR; candidate 0 of the selection)
-static int warpStreamCSR(spmat* dMat, double* dX, CONFIG cfg, double* dY) {
-    (void)cfg;
-    DevMat* d = descOf(dMat, "hipSpMVWarpPerRowCSR");
-    if (!d) return EXIT_FAILURE;
-    if (d->kind != Kind::CSR) { ERR("hipSpMVWarpPerRowCSR: handle is not CSR"); return EXIT_FAILURE; }
-    if (d->M == 0) return nothingToLaunch(d, nullptr);
-    Launch L(grid2d(d->nBlk2, WG_THREADS), dim3(WG_THREADS));
-    launchStream2<false>(d, dX, dY);
-    return L.finish("hipSpMVWarpPerRowCSR");
-}
-
-static int autoRun(spmat* dMat, double* dX, CONFIG cfg, double* dY, const char* who);
-
 int hipSpMVWarpPerRowCSR(spmat* dMat, double* dX, CONFIG cfg, double* dY) {
-    if (S.variantWarpCSR == 2) return autoRun(dMat, dX, cfg, dY, "hipSpMVWarpPerRowCSR");
-    if (S.variantWarpCSR == 1) return warpStreamCSR(dMat, dX, cfg, dY);
+    if (S.variantWarpCSR == 2) return autoRun(dMat, dX, cfg, dY, 0, "hipSpMVWarpPerRowCSR");
+    if (S.variantWarpCSR == 1) return streamReduce(dMat, dX, cfg, dY);
     DevMat* d = descOf(dMat, "hipSpMVWarpPerRowCSR");
     if (!d) return EXIT_FAILURE;
     if (d->kind != Kind::CSR) { ERR("hipSpMVWarpPerRowCSR: handle is not CSR"); return EXIT_FAILURE; }
@@ -603,11 +659,26 @@ int hipSpMVWarpPerRowCSR(spmat* dMat, double* dX, CONFIG cfg, double* dY) {
     return L.finish("hipSpMVWarpPerRowCSR");
 }
 
+// explicit launchers and queries work on the form last asked for with spmvHipBuild*Opt (default: arrival order)
+int hipSpMVTilesCSR(spmat* dMat, double* dX, CONFIG cfg, double* dY) {
+    (void)cfg;
+    DevMat* d = descOf(dMat, "hipSpMVTilesCSR");
+    return d ? tilesForm(dMat, dX, dY, d->tilesPref, "hipSpMVTilesCSR") : EXIT_FAILURE;
+}
+int hipSpMVStripesCSR(spmat* dMat, double* dX, CONFIG cfg, double* dY) {
+    (void)cfg;
+    DevMat* d = descOf(dMat, "hipSpMVStripesCSR");
+    return d ? stripesForm(dMat, dX, dY, d->stripesPref, "hipSpMVStripesCSR") : EXIT_FAILURE;
+}
+
 int spmvHipBuildTiles(spmat* dMat) {
     DevMat* d = descOf(dMat, "spmvHipBuildTiles");
     if (!d) return EXIT_FAILURE;
     if (d->kind != Kind::CSR) { ERR("spmvHipBuildTiles: handle is not CSR"); return EXIT_FAILURE; }
-    return buildTiles(d);
+    useTiles(d, d->tilesPref);
+    if (d->tiles) return EXIT_SUCCESS;
+    const spmvTilesOpts o{0, 0, -1, 0, 1};
+    return buildTiles(d, d->tilesPref ? &o : nullptr);
 }
 size_t spmvHipTilesBytes(spmat* dMat) {
     DevMat* d = descOf(dMat, "spmvHipTilesBytes");
@@ -640,13 +711,18 @@ int spmvHipBuildStripes(spmat* dMat) {
     DevMat* d = descOf(dMat, "spmvHipBuildStripes");
     if (!d) return EXIT_FAILURE;
     if (d->kind != Kind::CSR) { ERR("spmvHipBuildStripes: handle is not CSR"); return EXIT_FAILURE; }
-    return buildStripes(d);
+    useStripes(d, d->stripesPref);
+    if (d->stripes) return EXIT_SUCCESS;
+    const spmvStripesOpts o{0, 0, -1, -1, 1};
+    return buildStripes(d, d->stripesPref ? &o : nullptr);
 }
 int spmvHipBuildStripesOpt(spmat* dMat, const spmvStripesOpts* opts) {
     DevMat* d = descOf(dMat, "spmvHipBuildStripesOpt");
     if (!d || !opts) return EXIT_FAILURE;
     if (d->kind != Kind::CSR || d->M == 0 || d->NZ == 0) { ERR("spmvHipBuildStripesOpt: needs a non-empty CSR handle"); return EXIT_FAILURE; }
-    return buildStripes(d, opts);
+    if (buildStripes(d, opts)) return EXIT_FAILURE;
+    d->stripesPref = opts->deterministic != 0;       // what hipSpMVStripesCSR and the queries use from now on
+    return EXIT_SUCCESS;
 }
 size_t spmvHipStripesBytes(spmat* dMat) {
     DevMat* d = descOf(dMat, "spmvHipStripesBytes");
@@ -655,6 +731,7 @@ size_t spmvHipStripesBytes(spmat* dMat) {
 int spmvHipStripesInfo(spmat* dMat, spmvStripesInfo* info) {
     DevMat* d = descOf(dMat, "spmvHipStripesInfo");
     if (!d || !info) return EXIT_FAILURE;
+    useStripes(d, d->stripesPref);
     stripesInfo(d, info);
     return EXIT_SUCCESS;
 }
@@ -667,41 +744,19 @@ int spmvHipStripesShape(spmat* dMat, unsigned* nBins, unsigned* rowsPerBin, int*
     if (buildMs) *buildMs = i.buildMs;
     return EXIT_SUCCESS;
 }
-int hipSpMVStripesCSR(spmat* dMat, double* dX, CONFIG cfg, double* dY) {
-    (void)cfg;
-    DevMat* d = descOf(dMat, "hipSpMVStripesCSR");
-    if (!d) return EXIT_FAILURE;
-    if (d->kind != Kind::CSR) { ERR("hipSpMVStripesCSR: handle is not CSR"); return EXIT_FAILURE; }
-    if (d->M == 0 || d->NZ == 0) return nothingToLaunch(d, dY);         // nothing to sweep: y = 0
-    if (!d->stripes && buildStripes(d)) return EXIT_FAILURE;
-    Launch L(dim3(1), dim3(1));
-    dim3 grid, block;
-    if (enqueueStripes(d, dX, dY, S.stream, &grid, &block)) { ERR("hipSpMVStripesCSR: launch failed"); return EXIT_FAILURE; }
-    L.shape(grid, block);                            // the persistent grid that ran: min(bins, CUs) workgroups of 256 threads
-    return L.finish("hipSpMVStripesCSR");
-}
 
-int hipSpMVTilesCSR(spmat* dMat, double* dX, CONFIG cfg, double* dY) {
-    (void)cfg;
-    DevMat* d = descOf(dMat, "hipSpMVTilesCSR");
-    if (!d) return EXIT_FAILURE;
-    if (d->kind != Kind::CSR) { ERR("hipSpMVTilesCSR: handle is not CSR"); return EXIT_FAILURE; }
-    if (d->M == 0 || d->NZ == 0) return nothingToLaunch(d, dY);         // nothing to slice: y = 0
-    if (!d->tiles && buildTiles(d)) return EXIT_FAILURE;
-    uint32_t bins = 0, rowsPerBin = 0;
-    tilesShape(d, &bins, &rowsPerBin);
-    Launch L(grid2d((uint64_t)((bins + 7) / 8) * 8, 1024), dim3(1024));  // phase 2's shape (phase 1: one workgroup per slice piece)
-    if (enqueueTiles(d, dX, dY, S.stream)) { ERR("hipSpMVTilesCSR: launch failed"); return EXIT_FAILURE; }
-    return L.finish("hipSpMVTilesCSR");
-}
-
-// ---- the fastest reduction-order CSR launcher for THIS matrix, found by timing ----------------------------------
+// ---- the fastest CSR launcher for THIS matrix, found by timing --------------------------------------------------
 // Which kernel wins depends on where x lives relative to the caches (DESIGN.md sections 4, 7, 8): the LDS-stream
 // kernel when the columns of neighbouring rows meet in L1/L2 (narrow bands, small matrices), the stripes kernel
 // while x fits the Infinity Cache, the two-phase kernel beyond.  A caller of the reference picks a kernel by name
-// (CUDA_CSR_ROWS_WARP ...); hipSpMVAutoCSR -- and hipSpMVWarpPerRowCSR in its default variant 2, i.e. the reference's
-// name for "coalesced spans, on-chip reduction" -- pick by measurement, once per handle, on the caller's own x: every
-// eligible candidate computes y (one warm-up launch that also builds its format, AUTO_REPS timed ones), the fastest
+// (CUDA_CSR_ROWS, CUDA_CSR_ROWS_WARP ...); here the two names stand for two CONTRACTS, and inside each contract the
+// kernel is picked by measurement, once per handle, on the caller's own x:
+//   selection 0, reduction order free (hipSpMVAutoCSR, hipSpMVWarpPerRowCSR variant 2): LDS-stream kernel with the LDS
+//                segmented reduction / two-phase / stripes, sums in arrival order;
+//   selection 1, serial order (hipSpMVRowsCSR variant 2): LDS-stream kernel with one thread per row / the deterministic
+//                forms of the two-phase and the stripes kernel -- every candidate adds a row's products in ascending j,
+//                so all of them give the bits of the serial oracle and the choice is invisible in y.
+// Every eligible candidate computes y (one warm-up launch that also builds its format, AUTO_REPS timed ones), the fastest
 // stays, the formats of the others are released, and the chosen launcher runs once more so that y is its own.  The
 // first call is a normal -- slow -- SpMV and synchronises the stream even in enqueue-only mode.
 namespace {
@@ -709,13 +764,16 @@ constexpr int      AUTO_N = 3, AUTO_REPS = 3;
 constexpr uint64_t AUTO_MIN_NNZ = 1ull << 18;        // below this a launch is mostly latency: no private format pays
 constexpr uint64_t AUTO_STRIPES_X_BYTES = 256ull << 20;   // the stripes kernel re-reads x once per XCD and round of bins
 struct AutoCand { const char* name; SPMV_HIP* fn; };
-const AutoCand AUTO_CAND[AUTO_N] = {{"hipSpMVWarpPerRowCSR", &warpStreamCSR}, {"hipSpMVTilesCSR", &hipSpMVTilesCSR},
-                                    {"hipSpMVStripesCSR", &hipSpMVStripesCSR}};
+const AutoCand AUTO_CAND[2][AUTO_N] = {
+    {{"hipSpMVWarpPerRowCSR", &streamReduce}, {"hipSpMVTilesCSR", &tilesArrival}, {"hipSpMVStripesCSR", &stripesArrival}},
+    {{"hipSpMVRowsCSR", &streamSerial}, {"hipSpMVTilesCSR(deterministic)", &tilesSerial}, {"hipSpMVStripesCSR(deterministic)", &stripesSerial}}};
 
-int autoSelect(spmat* dMat, DevMat* d, double* dX, CONFIG cfg, double* dY) {
+int autoSelect(spmat* dMat, DevMat* d, int serial, double* dX, CONFIG cfg, double* dY) {
     const bool fmtOk = d->NZ >= AUTO_MIN_NNZ && d->NZ < IRP32_LIMIT;
     const bool eligible[AUTO_N] = {true, fmtOk, fmtOk && d->N * 8 <= AUTO_STRIPES_X_BYTES};
-    if (!fmtOk) { d->autoPick = 0; return EXIT_SUCCESS; }
+    if (!fmtOk) { d->autoPick[serial] = 0; return EXIT_SUCCESS; }
+    useTiles(d, serial != 0);
+    useStripes(d, serial != 0);
     const bool hadTiles = d->tiles != nullptr, hadStripes = d->stripes != nullptr;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     HIP_TRY(hipEventCreate(&e0));
@@ -725,28 +783,28 @@ int autoSelect(spmat* dMat, DevMat* d, double* dX, CONFIG cfg, double* dY) {
     float bestMs = 0;
     // Lower bound of a format kernel's time: its bytes per entry at the rate this HBM streams (MI355X_MICROARCH.md: 6.3 TB/s).
     // A candidate whose BOUND is no better than what has already been measured cannot win: its format (12 B/nnz of memory,
-    // tens of B/nnz of temporaries, on c5's scale seconds of allocation) is not built.  Order: no format, 12 B/nnz, 28 B/nnz.
+    // 12 B/nnz of temporaries) is not built.  Order: no format, 12 B/nnz, 28 B/nnz.
     const double boundMs[AUTO_N] = {0.0, (double)d->NZ * 28.0 / 6.3e12 * 1e3, (double)d->NZ * 12.0 / 6.3e12 * 1e3};
     const int order[AUTO_N] = {0, 2, 1};
     for (int k = 0; k < AUTO_N; ++k) {
         const int c = order[k];
         if (!eligible[c]) continue;
-        if (best >= 0 && boundMs[c] >= bestMs / AUTO_REPS) { d->autoMs[c] = 0; continue; }
+        if (best >= 0 && boundMs[c] >= bestMs / AUTO_REPS) { d->autoMs[serial][c] = 0; continue; }
         // enqueue-only throughout (the library's own timing events belong to the device of spmvHipInit; this may run on another
         // device's stream, spmvHipEnqueueAuto) and no host round trip inside e0..e1
         S.sync = false;
-        const int rcWarm = AUTO_CAND[c].fn(dMat, dX, cfg, dY) || hipStreamSynchronize(S.stream) != hipSuccess;   // warm-up + format build
+        const int rcWarm = AUTO_CAND[serial][c].fn(dMat, dX, cfg, dY) || hipStreamSynchronize(S.stream) != hipSuccess;   // warm-up + format build
         if (rcWarm) {                                                     // a candidate that fails is not a candidate ...
             (void)hipGetLastError();                                      // ... and must not leave its error behind for the next one
             continue;
         }
         bool ok = hipEventRecord(e0, S.stream) == hipSuccess;
-        for (int r = 0; ok && r < AUTO_REPS; ++r) ok = AUTO_CAND[c].fn(dMat, dX, cfg, dY) == EXIT_SUCCESS;
+        for (int r = 0; ok && r < AUTO_REPS; ++r) ok = AUTO_CAND[serial][c].fn(dMat, dX, cfg, dY) == EXIT_SUCCESS;
         float ms = 0;
         ok = ok && hipEventRecord(e1, S.stream) == hipSuccess && hipEventSynchronize(e1) == hipSuccess &&
              hipEventElapsedTime(&ms, e0, e1) == hipSuccess;
         if (!ok) { (void)hipGetLastError(); continue; }
-        d->autoMs[c] = ms / AUTO_REPS;
+        d->autoMs[serial][c] = ms / AUTO_REPS;
         if (best < 0 || ms < bestMs) { best = c; bestMs = ms; }
     }
     S.sync = wasSync;
@@ -754,49 +812,60 @@ int autoSelect(spmat* dMat, DevMat* d, double* dX, CONFIG cfg, double* dY) {
     (void)hipEventDestroy(e1);
     if (best < 0) { ERR("hipSpMVAutoCSR: no candidate kernel ran"); return EXIT_FAILURE; }
     // the losers' private copies of the matrix (12 B/nnz each) go; formats the caller built before stay
+    useTiles(d, serial != 0);
+    useStripes(d, serial != 0);
     if (best != 1 && d->tiles && !hadTiles) { freeTiles(d->tiles); d->tiles = nullptr; }
     if (best != 2 && d->stripes && !hadStripes) { freeStripes(d->stripes); d->stripes = nullptr; }
-    d->autoPick = best;
+    d->autoPick[serial] = best;
     return EXIT_SUCCESS;
 }
 }  // namespace
 
-static int autoRun(spmat* dMat, double* dX, CONFIG cfg, double* dY, const char* who) {
+static int autoRun(spmat* dMat, double* dX, CONFIG cfg, double* dY, int serial, const char* who) {
     DevMat* d = descOf(dMat, who);
     if (!d) return EXIT_FAILURE;
     if (d->kind != Kind::CSR) { ERR("%s: handle is not CSR", who); return EXIT_FAILURE; }
     if (d->M == 0) return nothingToLaunch(d, nullptr);
-    if (d->autoPick < 0 && autoSelect(dMat, d, dX, cfg, dY)) return EXIT_FAILURE;
-    return AUTO_CAND[d->autoPick].fn(dMat, dX, cfg, dY);               // (also after the selection: y then is the chosen kernel's own)
+    if (d->autoPick[serial] < 0 && autoSelect(dMat, d, serial, dX, cfg, dY)) return EXIT_FAILURE;
+    return AUTO_CAND[serial][d->autoPick[serial]].fn(dMat, dX, cfg, dY);   // (also after the selection: y then is the chosen kernel's own)
 }
 
-int hipSpMVAutoCSR(spmat* dMat, double* dX, CONFIG cfg, double* dY) { return autoRun(dMat, dX, cfg, dY, "hipSpMVAutoCSR"); }
+int hipSpMVAutoCSR(spmat* dMat, double* dX, CONFIG cfg, double* dY) { return autoRun(dMat, dX, cfg, dY, 0, "hipSpMVAutoCSR"); }
 
-const char* spmvHipAutoChoice(spmat* dMat, double* msPerCandidate) {
+static const char* autoChoice(spmat* dMat, int serial, double* msPerCandidate) {
     DevMat* d = descOf(dMat, "spmvHipAutoChoice");
-    if (!d || d->autoPick < 0) return nullptr;
-    if (msPerCandidate) for (int c = 0; c < AUTO_N; ++c) msPerCandidate[c] = d->autoMs[c];
-    return AUTO_CAND[d->autoPick].name;
+    if (!d || d->autoPick[serial] < 0) return nullptr;
+    if (msPerCandidate) for (int c = 0; c < AUTO_N; ++c) msPerCandidate[c] = d->autoMs[serial][c];
+    return AUTO_CAND[serial][d->autoPick[serial]].name;
 }
+const char* spmvHipAutoChoice(spmat* dMat, double* msPerCandidate) { return autoChoice(dMat, 0, msPerCandidate); }
+const char* spmvHipAutoChoiceRows(spmat* dMat, double* msPerCandidate) { return autoChoice(dMat, 1, msPerCandidate); }
 
-// enqueue-only form of the selection's launcher on an explicit stream (shard.hip: one stream per device); the first call
+// enqueue-only form of a selection's launcher on an explicit stream (shard.hip: one stream per device); the first call
 // for a handle measures the candidates on that stream and synchronises it
-int spmvHipEnqueueAuto(spmat* dMat, double* dX, double* dY, void* stream) {
+static int enqueueAuto(spmat* dMat, double* dX, double* dY, void* stream, int serial, const char* who) {
     hipStream_t keepStream = S.stream;
     const bool keepSync = S.sync;
     S.stream = static_cast<hipStream_t>(stream);
     S.sync = false;
-    const int rc = autoRun(dMat, dX, CONFIG{}, dY, "spmvHipEnqueueAuto");
+    const int rc = autoRun(dMat, dX, CONFIG{}, dY, serial, who);
     S.stream = keepStream;
     S.sync = keepSync;
     return rc;
 }
+int spmvHipEnqueueAuto(spmat* dMat, double* dX, double* dY, void* stream) { return enqueueAuto(dMat, dX, dY, stream, 0, "spmvHipEnqueueAuto"); }
+int spmvHipEnqueueAutoRows(spmat* dMat, double* dX, double* dY, void* stream) { return enqueueAuto(dMat, dX, dY, stream, 1, "spmvHipEnqueueAutoRows"); }
 
+// the two-phase format the explicit entry points below work on: the preferred form, built if missing
 static DevMat* tilesReady(spmat* dMat, const char* who) {
     DevMat* d = descOf(dMat, who);
     if (!d) return nullptr;
     if (d->kind != Kind::CSR || d->M == 0 || d->NZ == 0) { ERR("%s: needs a non-empty CSR handle", who); return nullptr; }
-    if (!d->tiles && buildTiles(d)) return nullptr;
+    useTiles(d, d->tilesPref);
+    if (!d->tiles) {
+        const spmvTilesOpts o{0, 0, -1, 0, 1};
+        if (buildTiles(d, d->tilesPref ? &o : nullptr)) return nullptr;
+    }
     return d;
 }
 
@@ -812,13 +881,17 @@ int spmvHipTilesShape(spmat* dMat, unsigned* nBins, unsigned* rowsPerBin) {
 int spmvHipBuildTilesOpt(spmat* dMat, const spmvTilesOpts* opts) {
     DevMat* d = descOf(dMat, "spmvHipBuildTilesOpt");
     if (!d) return EXIT_FAILURE;
+    if (!opts) return EXIT_FAILURE;
     if (d->kind != Kind::CSR || d->M == 0 || d->NZ == 0) { ERR("spmvHipBuildTilesOpt: needs a non-empty CSR handle"); return EXIT_FAILURE; }
-    return buildTiles(d, opts);
+    if (buildTiles(d, opts)) return EXIT_FAILURE;
+    d->tilesPref = opts->deterministic != 0;         // what hipSpMVTilesCSR, Expand / Reduce and the queries use from now on
+    return EXIT_SUCCESS;
 }
 
 int spmvHipTilesInfo(spmat* dMat, spmvTilesInfo* info) {
     DevMat* d = descOf(dMat, "spmvHipTilesInfo");
     if (!d || !info) return EXIT_FAILURE;
+    useTiles(d, d->tilesPref);
     tilesInfo(d, info);
     return EXIT_SUCCESS;
 }
@@ -907,6 +980,8 @@ int hipSpMVRowsELLNNTransposed(spmat* dMat, double* dX, CONFIG cfg, double* dY) 
     if (!d) return EXIT_FAILURE;
     if (d->kind != Kind::ELL_ROWMAJOR) { ERR("hipSpMVRowsELLNNTransposed: expects the row-major ELL upload (no ellTranspose)"); return EXIT_FAILURE; }
     if (d->M == 0) return nothingToLaunch(d, nullptr);
+    if (S.variantEllRowMajor == 1 && cfg.blockSize.x == 0 && d->pitch && d->pitch <= (size_t)STREAM_NNZ)
+        return launchEllStream(d, S.ellRowLens && d->RL, true, dX, dY, "hipSpMVRowsELLNNTransposed");
     const unsigned bt = blockThreads(cfg, BLOCKS_1D, 1024);
     const dim3 grid = grid2d((d->M + bt - 1) / bt, bt), block(bt);
     Launch L(grid, block);
@@ -921,7 +996,10 @@ int hipSpMVWarpsPerRowELLNTrasposed(spmat* dMat, double* dX, CONFIG cfg, double*
     if (!d) return EXIT_FAILURE;
     if (d->kind != Kind::ELL_ROWMAJOR) { ERR("hipSpMVWarpsPerRowELLNTrasposed: expects the row-major ELL upload (no ellTranspose)"); return EXIT_FAILURE; }
     if (d->M == 0) return nothingToLaunch(d, nullptr);
-    // lanes per row: the smallest power of two covering the slots, 4..64
+    const bool rl = S.ellRowLens && d->RL;
+    if (d->pitch && d->pitch <= (size_t)STREAM_NNZ)   // a row fits a block of the LDS-stream kernel: dense span loads, LDS segmented reduction
+        return launchEllStream(d, rl, false, dX, dY, "hipSpMVWarpsPerRowELLNTrasposed");
+    // longer rows: G lanes per row -- the smallest power of two covering the slots, 4..64
     int G = 4;
     while (G < WAVE && (uint64_t)G < d->K) G <<= 1;
     const unsigned bt = 256;
@@ -929,7 +1007,6 @@ int hipSpMVWarpsPerRowELLNTrasposed(spmat* dMat, double* dX, CONFIG cfg, double*
     const uint64_t threads = (d->M + ELL_GROUP_ROWS - 1) / ELL_GROUP_ROWS * (uint64_t)G;     // a group of G lanes owns 4 rows
     const dim3 grid = grid2d((threads + bt - 1) / bt, bt), block(bt);
     Launch L(grid, block);
-    const bool rl = S.ellRowLens && d->RL;
     switch (G) {
         case 4:  launchEllGroup<4>(d, rl, grid, block, dX, dY); break;
         case 8:  launchEllGroup<8>(d, rl, grid, block, dX, dY); break;

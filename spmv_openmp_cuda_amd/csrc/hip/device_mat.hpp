@@ -48,11 +48,18 @@ struct DevMat {
     uint4*    blkInfo = nullptr;    // {first row, #rows, #nnz, long-row flag}
     uint64_t* blkBase = nullptr;    // nnz offset of the block
     uint32_t  nBlk2 = 0, nLong2 = 0;
-    TileFormat* tiles = nullptr;    // built lazily by hipSpMVTilesCSR / spmvHipBuildTiles
+    // The two-phase and the stripes format exist in two FORMS each -- arrival-order and deterministic (serial-order) sums --
+    // and a handle may hold both: `tiles` / `stripes` is the ACTIVE one (what the functions of tiles.hip / stripes.hip work
+    // on), `*Alt` the other.  useTiles / useStripes make the requested form the active one (possibly a null slot still to
+    // be built).  `*Pref` is the form the explicit launchers and queries use: set by spmvHipBuildTilesOpt / ...StripesOpt.
+    TileFormat* tiles = nullptr, *tilesAlt = nullptr;         // built lazily by hipSpMVTilesCSR / spmvHipBuildTiles / the selections
+    StripeFormat* stripes = nullptr, *stripesAlt = nullptr;   // built lazily by hipSpMVStripesCSR / spmvHipBuildStripes / the selections
+    bool      tilesPref = false, stripesPref = false;
     SellFormat* sell = nullptr;     // built lazily by hipSpMVRowsSELL / spmvHipBuildSell
-    StripeFormat* stripes = nullptr; // built lazily by hipSpMVStripesCSR / spmvHipBuildStripes
-    int       autoPick = -1;        // hipSpMVAutoCSR: index of the launcher chosen for this matrix (-1: not chosen yet)
-    float     autoMs[3] = {0, 0, 0}; // ... and what each candidate took (0 = not tried)
+    // the selections: [0] among the reduction-order kernels (hipSpMVAutoCSR, hipSpMVWarpPerRowCSR), [1] among the
+    // serial-order kernels (hipSpMVRowsCSR): index of the launcher chosen for this matrix (-1: not chosen yet) ...
+    int       autoPick[2] = {-1, -1};
+    float     autoMs[2][3] = {{0, 0, 0}, {0, 0, 0}};          // ... and what each candidate took (0 = not tried)
 };
 
 int  buildSell(DevMat* d);                                      // sell.hip
@@ -62,6 +69,7 @@ size_t sellBytes(const DevMat* d);
 
 int  buildStripes(DevMat* d, const spmvStripesOpts* opts = nullptr);   // stripes.hip; explicit options replace an existing format
 void freeStripes(StripeFormat* f);
+void useStripes(DevMat* d, bool deterministic);                 // make that form the active one (d->stripes may then be null)
 int  enqueueStripes(DevMat* d, const double* x, double* y, hipStream_t stream, dim3* grid = nullptr, dim3* block = nullptr);
 size_t stripesBytes(const DevMat* d);
 void stripesInfo(const DevMat* d, spmvStripesInfo* out);
@@ -69,6 +77,7 @@ void stripesInfo(const DevMat* d, spmvStripesInfo* out);
 int  buildTiles(DevMat* d, const spmvTilesOpts* opts = nullptr); // tiles.hip; explicit options replace an existing format
 void tilesInfo(const DevMat* d, spmvTilesInfo* out);
 void freeTiles(TileFormat* t);
+void useTiles(DevMat* d, bool deterministic);                   // make that form the active one (d->tiles may then be null)
 void freeTilesWorkspace();                                      // the per-device product workspace (8 B/nnz of the largest matrix)
 int  enqueueTiles(DevMat* d, const double* x, double* y, hipStream_t stream);
 int  enqueueTilesExpand(DevMat* d, const double* x, hipStream_t stream);

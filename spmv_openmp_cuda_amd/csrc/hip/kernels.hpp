@@ -333,4 +333,83 @@ __global__ __launch_bounds__(256) void ell_rowmajor_group(
     }
 }
 
+// Row-major ELL through the LDS-stream machinery (the default of hipSpMVWarpsPerRowELLNTrasposed while a row fits a block).
+// With the pitch equal to the slot count (rounded up to 2) the padded matrix IS one contiguous array: workgroup b owns
+// Rb = floor(2048 / pitch) consecutive rows, i.e. the span of Rb * pitch cells starting at row b*Rb:
+//   1. lanes load cells tid, tid + 256, ... of the span (fully coalesced, non-temporal), gather x and park the rounded
+//      product in LDS -- padding cells {JA = 0, AS = 0.0} included: no test, no division in the streaming phase;
+//   2. L lanes per row (largest power of two with L * rows <= 256) sum the row's first RL[row] cells (USE_RL: the row-length
+//      early exit -- padding products are never added) or all `slots` cells (as the reference kernel does: padding adds
+//      0.0 * x[0]) lane-strided, then a shuffle tree.
+// The lanes-per-row kernel above reads a row with one wavefront instruction per 64/G rows and idles the lanes beyond the
+// slot count (18 slots: 14 of 32); this one keeps every lane on a dense stream whatever the slot count, like its CSR
+// sibling csr_stream2_kernel (stencil 500x100x100, 18 slots: 0.38 -> see profiles/r03_*).
+// SEQ: one thread per row adds the row's cells in ascending slot order instead (the summation order of the thread-per-row
+// kernels: bit-identical to them and to the serial oracle) -- hipSpMVRowsELLNNTransposed's default: the row-major
+// thread-per-row kernel is uncoalesced by construction (a lane's loads are a pitch apart), the same sums fed from a
+// coalesced span are not.
+template <bool USE_RL, bool SEQ>
+__global__ __launch_bounds__(WG_THREADS) void ell_stream_kernel(
+    uint32_t rows, uint32_t slots, uint32_t pitch, uint32_t rowsPerBlk, uint64_t nBlk, const uint32_t* __restrict__ JA,
+    const double* __restrict__ AS, const uint32_t* __restrict__ RL, const double* __restrict__ x, double* __restrict__ y) {
+    __shared__ double prod[STREAM_NNZ];
+    const uint32_t tid = threadIdx.x;
+    uint64_t blk = linear_block();
+    if (blk >= nBlk) return;
+    {   // XCD-contiguous deal (workgroups b, b + 8, ... share an XCD): neighbouring rows -- and their x window -- meet in one L2
+        const uint64_t a = nBlk / 8, rem = nBlk % 8, xcd = blk % 8;
+        blk = xcd * a + (xcd < rem ? xcd : rem) + blk / 8;
+    }
+    const uint64_t r0 = blk * rowsPerBlk;
+    const uint32_t R = (uint32_t)min((uint64_t)rowsPerBlk, rows - r0);
+    const uint32_t n = R * pitch;                    // <= STREAM_NNZ
+    const uint64_t base = r0 * pitch;
+    {
+        uint32_t col[STREAM_UNROLL];
+        double   val[STREAM_UNROLL];
+#pragma unroll
+        for (int u = 0; u < STREAM_UNROLL; ++u) {
+            const uint32_t k = tid + u * WG_THREADS;
+            const bool in = k < n;
+            col[u] = in ? stream_load(JA + base + k) : 0u;
+            val[u] = in ? stream_load(AS + base + k) : 0.0;
+        }
+        double xv[STREAM_UNROLL];
+#pragma unroll
+        for (int u = 0; u < STREAM_UNROLL; ++u) xv[u] = x[col[u]];
+#pragma unroll
+        for (int u = 0; u < STREAM_UNROLL; ++u) {
+            const uint32_t k = tid + u * WG_THREADS;
+            if (k < n) prod[k] = val[u] * xv[u];
+        }
+    }
+    __syncthreads();
+    if (SEQ) {
+        for (uint32_t rr = tid; rr < R; rr += WG_THREADS) {
+            const uint32_t len = USE_RL ? RL[r0 + rr] : slots;
+            const uint32_t s = rr * pitch;
+            double acc = 0;
+            for (uint32_t j = 0; j < len; ++j) acc += prod[s + j];
+            y[r0 + rr] = acc;
+        }
+        return;
+    }
+    int L = 1;
+    while (L < WAVE && 2u * L * R <= (uint32_t)WG_THREADS) L <<= 1;
+    const uint32_t rowsPerPass = WG_THREADS / L;
+    const uint32_t g = tid / L, l = tid % L;
+    const uint32_t passes = (R + rowsPerPass - 1) / rowsPerPass;
+    for (uint32_t p = 0; p < passes; ++p) {
+        const uint32_t rr = p * rowsPerPass + g;
+        const bool live = rr < R;
+        uint32_t len = 0;
+        if (live) len = USE_RL ? RL[r0 + rr] : slots;
+        const uint32_t s = rr * pitch;
+        double acc = 0;
+        for (uint32_t j = l; j < len; j += L) acc += prod[s + j];
+        acc = group_sum_rt(acc, L);
+        if (live && l == 0) y[r0 + rr] = acc;
+    }
+}
+
 }  // namespace spmvhip

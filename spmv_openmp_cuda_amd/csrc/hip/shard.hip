@@ -74,7 +74,7 @@ struct Shard {
     std::vector<hipEvent_t> evK0, evK1;      // [nDev*G] around each group's kernel
     std::vector<ncclComm_t> comms;
     bool useRccl = false;
-    bool selected = false;                   // mode 1: the per-block kernel selection has run
+    bool selected[2] = {false, false};       // per mode: the per-block kernel selection has run
     ulong lo(int d, int g) const { return bounds[(size_t)d * G + g]; }
     ulong hi(int d, int g) const { return bounds[(size_t)d * G + g + 1]; }
 };
@@ -98,7 +98,7 @@ int shardStep(Shard* sh, const double* hX, int mode, bool timed) {
             double* slot = sh->dYpad[k] + (size_t)d * pad;
             if (timed) HIP_TRY(hipEventRecord(sh->evK0[k], sh->compute[d]));
             const int rc = mode ? spmvHipEnqueueAuto(&sh->mats[k], sh->dX[d], slot, sh->compute[d])
-                                : spmvHipEnqueueCSR(&sh->mats[k], 0, sh->dX[d], slot, sh->compute[d]);
+                                : spmvHipEnqueueAutoRows(&sh->mats[k], sh->dX[d], slot, sh->compute[d]);
             if (rc) return EXIT_FAILURE;
             HIP_TRY(hipEventRecord(sh->evK1[k], sh->compute[d]));
             HIP_TRY(hipStreamWaitEvent(sh->gather[d], sh->evK1[k], 0));      // (the first group's wait also orders the poison before the gather)
@@ -211,9 +211,9 @@ int spmvHipSpMVSharded(void* handle, const double* hX, int mode, double* hY, dou
     if (!sh || !hX || !hY) return EXIT_FAILURE;
     DeviceGuard guard;
     const int n = sh->nDev, G = sh->G;
-    if (mode && !sh->selected) {
+    if (!sh->selected[mode != 0]) {
         if (shardStep(sh, hX, mode, false)) return EXIT_FAILURE;
-        sh->selected = true;
+        sh->selected[mode != 0] = true;
     }
     if (shardStep(sh, hX, mode, true)) return EXIT_FAILURE;
     double kmax = 0, tmax = 0;

@@ -402,7 +402,14 @@ void freeStripes(StripeFormat* f) {
     delete f;
 }
 
-size_t stripesBytes(const DevMat* d) { return d->stripes ? d->stripes->bytes : 0; }
+size_t stripesBytes(const DevMat* d) { return (d->stripes ? d->stripes->bytes : 0) + (d->stripesAlt ? d->stripesAlt->bytes : 0); }
+
+// a handle holds at most one format of each form; the requested one becomes the active slot
+void useStripes(DevMat* d, bool deterministic) {
+    if (d->stripes && d->stripes->det == deterministic) return;
+    if (d->stripes || d->stripesAlt) std::swap(d->stripes, d->stripesAlt);
+    if (d->stripes && d->stripes->det != deterministic) std::swap(d->stripes, d->stripesAlt);
+}
 
 void stripesInfo(const DevMat* d, spmvStripesInfo* out) {
     memset(out, 0, sizeof *out);
@@ -412,8 +419,10 @@ void stripesInfo(const DevMat* d, spmvStripesInfo* out) {
     out->wide = f->wide ? 1 : 0; out->deterministic = f->det ? 1 : 0; out->buildMs = f->buildMs; out->bytes = f->bytes;
 }
 
-// `opts` == nullptr: automatic format, kept if one exists.  Explicit options: an existing format is replaced.
+// `opts` == nullptr: automatic arrival-order format, kept if one exists.  Explicit options: the existing format of that FORM
+// is replaced (the other form, if the handle holds it, is untouched).
 int buildStripes(DevMat* d, const spmvStripesOpts* opts) {
+    useStripes(d, opts && opts->deterministic);
     if (d->stripes && !opts) return EXIT_SUCCESS;
     if (d->kind != Kind::CSR) return EXIT_FAILURE;
     const spmvStripesOpts o = opts ? *opts : spmvStripesOpts{0, 0, -1, -1, 0};

@@ -730,8 +730,17 @@ void freeTiles(TileFormat* t) {
     delete t;
 }
 
-// `opts` == nullptr: automatic format, kept if one exists.  Explicit options: an existing format is replaced.
+// a handle holds at most one format of each form; the requested one becomes the active slot
+void useTiles(DevMat* d, bool deterministic) {
+    if (d->tiles && d->tiles->det == deterministic) return;
+    if (d->tiles || d->tilesAlt) std::swap(d->tiles, d->tilesAlt);
+    if (d->tiles && d->tiles->det != deterministic) std::swap(d->tiles, d->tilesAlt);      // (only one slot was filled, with the other form)
+}
+
+// `opts` == nullptr: automatic arrival-order format, kept if one exists.  Explicit options: the existing format of that FORM
+// is replaced (the other form, if the handle holds it, is untouched).
 int buildTiles(DevMat* d, const spmvTilesOpts* opts) {
+    useTiles(d, opts && opts->deterministic);
     if (d->tiles && !opts) return EXIT_SUCCESS;
     if (d->kind != Kind::CSR) return EXIT_FAILURE;
     const spmvTilesOpts o = opts ? *opts : spmvTilesOpts{0, 0, -1, 0, 0};
@@ -1008,7 +1017,7 @@ int buildTiles(DevMat* d, const spmvTilesOpts* opts) {
     return EXIT_SUCCESS;
 }
 
-size_t tilesBytes(const DevMat* d) { return d->tiles ? d->tiles->bytes : 0; }
+size_t tilesBytes(const DevMat* d) { return (d->tiles ? d->tiles->bytes : 0) + (d->tilesAlt ? d->tilesAlt->bytes : 0); }
 
 void tilesInfo(const DevMat* d, spmvTilesInfo* out) {
     memset(out, 0, sizeof *out);

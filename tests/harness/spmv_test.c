@@ -158,10 +158,10 @@ int main(int argc, char** argv) {
             hprintsf("@computing SpMV   with func: CUDA CSR %u at:%p\n", f, (void*)SpmvCUDA_CSRFuncs[f]);
             if (testSpMVImplHip(SpmvCUDA_CSRFuncs[f], &dMat, mat->M, dVect, dOutV, outV, oracleOut, &avg)) goto _free;
             printf("#tight CSR %u\tmax|dy|/sum|a x|:%le\n", f, oracleScaledError(matCSR, vector, oracleOut, outV));
-            if (f == SpmvCUDA_CSRFuncs_WarpPerRowIdx || f == SpmvCUDA_CSRFuncs_AutoIdx) {   /* which kernel the name resolved to */
+            if (f == 0 || f == SpmvCUDA_CSRFuncs_WarpPerRowIdx || f == SpmvCUDA_CSRFuncs_AutoIdx) {   /* which kernel the name resolved to */
                 double ms3[3] = {0, 0, 0};
-                const char* pick = spmvHipAutoChoice(&dMat, ms3);
-                printf("#auto CSR %u\tpick:%s\tmsWarpStream:%le msTiles:%le msStripes:%le\n", f, pick ? pick : "(none)", ms3[0], ms3[1], ms3[2]);
+                const char* pick = f == 0 ? spmvHipAutoChoiceRows(&dMat, ms3) : spmvHipAutoChoice(&dMat, ms3);
+                printf("#auto CSR %u\tpick:%s\tmsStream:%le msTiles:%le msStripes:%le\n", f, pick ? pick : "(none)", ms3[0], ms3[1], ms3[2]);
             }
             char tagc[32];
             snprintf(tagc, sizeof tagc, "HIP CSR %u", f);

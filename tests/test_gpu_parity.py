@@ -99,16 +99,18 @@ def _run(api, launcher, dmat, x, rows):
 @pytest.fixture(autouse=True)
 def _default_variants(api):
     """every test starts (and leaves) with the default kernel variants"""
-    api.set_variant("hipSpMVRowsCSR", 1)
+    api.set_variant("hipSpMVRowsCSR", 2)
     api.set_variant("hipSpMVWarpPerRowCSR", 2)
+    api.set_variant("hipSpMVRowsELLNNTransposed", 1)
     yield
-    api.set_variant("hipSpMVRowsCSR", 1)
+    api.set_variant("hipSpMVRowsCSR", 2)
     api.set_variant("hipSpMVWarpPerRowCSR", 2)
+    api.set_variant("hipSpMVRowsELLNNTransposed", 1)
 
 
 @pytest.mark.parametrize("name", list(CASES))
 @pytest.mark.parametrize("launcher,variant,exact", [
-    ("hipSpMVRowsCSR", 0, True), ("hipSpMVRowsCSR", 1, True),
+    ("hipSpMVRowsCSR", 0, True), ("hipSpMVRowsCSR", 1, True), ("hipSpMVRowsCSR", 2, True),
     ("hipSpMVWarpPerRowCSR", 0, False), ("hipSpMVWarpPerRowCSR", 1, False), ("hipSpMVWarpPerRowCSR", 2, False),
     ("hipSpMVTilesCSR", -1, False), ("hipSpMVStripesCSR", -1, False), ("hipSpMVRowsSELL", -1, False)])
 def test_csr(api, oracle, name, launcher, variant, exact):
@@ -146,9 +148,13 @@ def test_csr(api, oracle, name, launcher, variant, exact):
 @pytest.mark.parametrize("rowlens", [True, False])
 @pytest.mark.parametrize("launcher,transposed,exact", [
     ("hipSpMVRowsELL", True, True),
-    ("hipSpMVRowsELLNNTransposed", False, True),
+    ("hipSpMVRowsELLNNTransposed", False, True),          # default variant 1: LDS-stream kernel, one thread sums its row
+    ("hipSpMVRowsELLNNTransposed:0", False, True),        # variant 0: a thread walks its row in global memory
     ("hipSpMVWarpsPerRowELLNTrasposed", False, False)])
 def test_ell(api, oracle, name, rowlens, launcher, transposed, exact):
+    if launcher.endswith(":0"):
+        launcher = launcher[:-2]
+        api.set_variant(launcher, 0)
     M, N, IRP, JA, AS = CASES[name]
     x = _x(np.random.default_rng(8), N)
     y_ref = oracle.csr_serial(IRP, JA, AS, x)
@@ -247,8 +253,8 @@ def test_full_size_spot_checks(api, oracle, key):
         refs.append(oracle.csr_serial_dev((irp[r0:r1 + 1] - irp[r0]).astype(np.uint32), ja, as_, x))
     expect = b"hipSpMVTilesCSR" if key == "c5" else b"hipSpMVStripesCSR"
     for launcher, variant, exact in (("hipSpMVAutoCSR", -1, False), ("hipSpMVWarpPerRowCSR", 2, False), ("hipSpMVWarpPerRowCSR", 1, False),
-                                     ("hipSpMVRowsCSR", 1, True), ("hipSpMVTilesCSR", -1, False), ("hipSpMVStripesCSR", -1, False),
-                                     ("hipSpMVRowsSELL", -1, False)):
+                                     ("hipSpMVRowsCSR", 1, True), ("hipSpMVRowsCSR", 2, True), ("hipSpMVTilesCSR", -1, False),
+                                     ("hipSpMVStripesCSR", -1, False), ("hipSpMVRowsSELL", -1, False)):
         if variant >= 0:
             api.set_variant(launcher, variant)
         dy.poison()
@@ -264,6 +270,11 @@ def test_full_size_spot_checks(api, oracle, key):
             assert api.lib.spmvHipAutoChoice(C.byref(dm.handle), None) == expect
             tb, sb = api.lib.spmvHipTilesBytes(C.byref(dm.handle)), api.lib.spmvHipStripesBytes(C.byref(dm.handle))
             assert (tb > 0) == (expect == b"hipSpMVTilesCSR") and (sb > 0) == (expect == b"hipSpMVStripesCSR")
+        if (launcher, variant) == ("hipSpMVRowsCSR", 2):    # the serial-order selection: measured, a format kernel wins at this size
+            ms = (C.c_double * 3)()
+            pick = api.lib.spmvHipAutoChoiceRows(C.byref(dm.handle), ms)
+            assert pick in (b"hipSpMVTilesCSR(deterministic)", b"hipSpMVStripesCSR(deterministic)"), pick
+            assert ms[0] > 0 and min(t for t in ms if t > 0) == ms[(b"hipSpMVRowsCSR", b"hipSpMVTilesCSR(deterministic)", b"hipSpMVStripesCSR(deterministic)").index(pick)]
         # linearity (size-independent property): A(2x) == 2 A(x) exactly in binary fp
         dx2 = api.DeviceVector(w.N).up(2.0 * x)
         dy.poison()
@@ -310,7 +321,7 @@ def test_64bit_row_pointers_small(api, oracle):
     dm = api.DeviceMatrix()
     assert api.lib.spmvHipAdoptCSR(C.byref(dm.handle), M, N, JA.size, d_irp.ptr, 8, d_ja.ptr, d_as.ptr, None) == 0
     dm.keep = [d_irp, d_ja, d_as]
-    for launcher, variants, exact in (("hipSpMVRowsCSR", (0, 1), True), ("hipSpMVWarpPerRowCSR", (0, 1, 2), False),
+    for launcher, variants, exact in (("hipSpMVRowsCSR", (0, 1, 2), True), ("hipSpMVWarpPerRowCSR", (0, 1, 2), False),
                                       ("hipSpMVTilesCSR", (-1,), False), ("hipSpMVStripesCSR", (-1,), False),
                                       ("hipSpMVRowsSELL", (-1,), False)):
         for v in variants:
@@ -611,6 +622,19 @@ def test_auto_launcher_picks_and_remembers(api, oracle):
     # only the winner keeps a private copy of the matrix
     tb, sb = api.lib.spmvHipTilesBytes(C.byref(d2.handle)), api.lib.spmvHipStripesBytes(C.byref(d2.handle))
     assert (tb > 0) == (name == b"hipSpMVTilesCSR") and (sb > 0) == (name == b"hipSpMVStripesCSR")
+    # the serial-order selection (hipSpMVRowsCSR, default variant) is made separately, keeps its own winner beside the
+    # other selection's, and whatever it picks gives the bits of the serial oracle -- on the first call and later
+    assert api.lib.spmvHipAutoChoiceRows(C.byref(d2.handle), None) is None
+    for call in range(3):
+        yr = _run(api, "hipSpMVRowsCSR", d2, x2, M2)
+        assert np.array_equal(yr, y2_ref), call
+        rname = api.lib.spmvHipAutoChoiceRows(C.byref(d2.handle), ms)
+        assert rname in (b"hipSpMVRowsCSR", b"hipSpMVTilesCSR(deterministic)", b"hipSpMVStripesCSR(deterministic)") and all(t > 0 for t in ms)
+    assert api.lib.spmvHipAutoChoice(C.byref(d2.handle), None) == name              # untouched
+    y2 = _run(api, "hipSpMVAutoCSR", d2, x2, M2)                                    # and still runs its own format
+    assert tight_error(IRP2, JA2, AS2, x2, y2_ref, y2) <= TIGHT
+    tb2, sb2 = api.lib.spmvHipTilesBytes(C.byref(d2.handle)), api.lib.spmvHipStripesBytes(C.byref(d2.handle))
+    assert tb2 >= tb and sb2 >= sb and (tb2 + sb2 > tb + sb) == (rname != b"hipSpMVRowsCSR")
     d2.free()
     # an ELL handle is refused
     Me, Ne, IRPe, JAe, ASe = CASES["cage4-shaped"]

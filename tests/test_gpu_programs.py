@@ -77,8 +77,8 @@ def test_harness_all_implementations_pass(name):
 
 def test_harness_reports_the_kernel_behind_the_reference_names(tmp_path):
     """On a matrix large enough for the selection to measure (>= 2^18 entries) the harness shows which kernel the
-    reference's name SpmvCUDA_CSRFuncs[SpmvCUDA_CSRFuncs_WarpPerRowIdx] (src/include/SpMV.h:130-134) resolved to -- the
-    same one hipSpMVAutoCSR picks -- and every implementation still passes the gate."""
+    reference's names SpmvCUDA_CSRFuncs[0] (serial-order selection) and SpmvCUDA_CSRFuncs[SpmvCUDA_CSRFuncs_WarpPerRowIdx]
+    (src/include/SpMV.h:130-134; the same one hipSpMVAutoCSR picks) resolved to, and every implementation still passes the gate."""
     rng = np.random.default_rng(41)
     M = N = 30_000
     IRP, JA, AS = random_csr(rng, M, N, np.full(M, 10))
@@ -91,9 +91,9 @@ def test_harness_reports_the_kernel_behind_the_reference_names(tmp_path):
     r = subprocess.run([HARNESS, str(mtx), "RNDVECT", "CUDA_ONLY"], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     picks = [l for l in r.stdout.splitlines() if l.startswith("#auto CSR")]
-    assert len(picks) == 2 and picks[0].startswith("#auto CSR 1\tpick:hipSpMV") and picks[1].startswith("#auto CSR 5\tpick:hipSpMV")
-    assert picks[0].split("\t")[1] == picks[1].split("\t")[1]
-    assert "msStripes:0.0" not in picks[1]                    # the candidates were really measured
+    assert len(picks) == 3 and picks[0].startswith("#auto CSR 0\tpick:hipSpMV") and picks[1].startswith("#auto CSR 1\tpick:hipSpMV")
+    assert picks[2].startswith("#auto CSR 5\tpick:hipSpMV") and picks[1].split("\t")[1] == picks[2].split("\t")[1]
+    assert all("msStripes:0.0" not in p for p in picks)       # the candidates were really measured
 
 
 def test_harness_thread_sweep():

@@ -96,6 +96,122 @@ def test_loader_details(tmp_path):
     assert (z.M, z.N, z.NZ) == (4, 5, 0) and list(_arr(z.IRP, 5, np.uint64)) == [0] * 5
 
 
+def test_parallel_parser_reads_what_fscanf_reads(tmp_path):
+    """The in-memory parser (csrc/host/mmfast.c; every regular file goes through it): values in every notation -- short
+    decimals and exponents (exact fast path), 16-17 significant digits, subnormals, huge exponents (strtod) -- must be
+    the correctly rounded doubles fscanf's %lf gives, i.e. Python's float() of the same token; several chunks (the file
+    is cut at line ends and parsed by all cores) must come back in file order."""
+    rng = np.random.default_rng(11)
+    M, N, per = 30_000, 900, 6
+    cols = np.sort(np.stack([rng.choice(N, per, replace=False) for _ in range(M)]), axis=1)
+    tokens = []
+    specials = ["1e22", "1e23", "123456789012345", "1234567890123456", "0.1e-310", "4.9e-324", "1.7976931348623157e308", "-0.0",
+                "+5", "007.250", ".5", "5.", "1E+2", "2.2250738585072014e-308", "9007199254740993", "0.30000000000000004"]
+    for i in range(M * per):
+        k = i % 7
+        if i < len(specials):
+            tokens.append(specials[i])
+        elif k == 0:
+            tokens.append(repr(float(rng.standard_normal() * 10.0 ** rng.integers(-30, 30))))     # 17 significant digits
+        elif k == 1:
+            tokens.append(f"{rng.integers(-99999, 99999) / 1000:.3f}")
+        elif k == 2:
+            tokens.append(f"{rng.integers(1, 10**9)}e{rng.integers(-25, 25)}")
+        elif k == 3:
+            tokens.append(str(int(rng.integers(-10**6, 10**6))))
+        elif k == 4:
+            tokens.append(f"{rng.random():.15g}")
+        elif k == 5:
+            tokens.append(f"{rng.random() * 1e-5:.12e}")
+        else:
+            tokens.append(f"{rng.integers(1, 2047) / 1024}")
+    lines = ["%%MatrixMarket matrix coordinate real general", f"{M} {N} {M * per}"]
+    i = 0
+    for r in range(M):
+        for c in cols[r]:
+            lines.append(f"{r + 1} {c + 1} {tokens[i]}" if i % 5 else f"  {r + 1}\t{c + 1}   {tokens[i]}  ")     # odd spacing too
+            i += 1
+    path = _write(tmp_path, "\n".join(lines) + "\n")
+    assert os.path.getsize(path) > 4 * 65536                    # several chunks
+    m = H.MMtoCSR(path).contents
+    assert (m.M, m.N, m.NZ) == (M, N, M * per)
+    assert np.array_equal(_arr(m.JA, m.NZ, np.uint64), cols.reshape(-1).astype(np.uint64))
+    got = _arr(m.AS, m.NZ, np.float64)
+    want = np.array([float(t) for t in tokens])
+    assert np.array_equal(got.view(np.uint64), want.view(np.uint64))            # bit for bit, -0.0 and subnormals included
+
+
+def test_parallel_parser_symmetric_pattern_and_fallback(tmp_path):
+    """Symmetric + pattern over several chunks (mirrored entries right behind their originals, so every row still sees
+    ascending columns); a file whose entries straddle line ends -- legal for fscanf, not for a line-cut parallel parse --
+    is still read (serial fallback); errors found by the parallel parser are reported as errors."""
+    n = 20_000
+    ent = []                                                   # lower triangle, column-major: what symmetric files look like
+    rng = np.random.default_rng(5)
+    for c in range(n):
+        ent.append((c, c))
+        for r in sorted(set(int(v) for v in rng.integers(c + 1, min(n, c + 40), size=3)) if c + 1 < n else []):
+            ent.append((r, c))
+    text = "%%MatrixMarket matrix coordinate pattern symmetric\n" + f"{n} {n} {len(ent)}\n" + "".join(f"{r + 1} {c + 1}\n" for r, c in ent)
+    path = _write(tmp_path, text, "sym.mtx")
+    assert os.path.getsize(path) > 4 * 65536
+    m = H.MMtoCSR(path).contents
+    import scipy.sparse as sp
+    rows = np.array([e[0] for e in ent] + [e[1] for e in ent if e[0] != e[1]])
+    colsv = np.array([e[1] for e in ent] + [e[0] for e in ent if e[0] != e[1]])
+    ref = sp.csr_matrix((np.ones(rows.size), (rows, colsv)), shape=(n, n))
+    ref.sort_indices()
+    assert m.NZ == ref.nnz and np.array_equal(_arr(m.IRP, n + 1, np.uint64), ref.indptr.astype(np.uint64))
+    assert np.array_equal(_arr(m.JA, m.NZ, np.uint64), ref.indices.astype(np.uint64)) and np.all(_arr(m.AS, m.NZ, np.float64) == 1.0)
+    # entries straddling lines, > 64 KiB so that a chunk boundary falls inside the odd layout
+    body = "".join(f"{r + 1}\n{r + 1} {0.5 + r}\n" for r in range(12_000))
+    odd = H.MMtoCSR(_write(tmp_path, "%%MatrixMarket matrix coordinate real general\n12000 12000 12000\n" + body, "odd.mtx"))
+    assert odd, "the serial fallback must read a file whose entries span lines"
+    o = odd.contents
+    assert o.NZ == 12000 and np.array_equal(_arr(o.AS, 12000, np.float64), 0.5 + np.arange(12000))
+    # errors deep inside a large file
+    big = ["%%MatrixMarket matrix coordinate real general", "50000 50000 50000"] + [f"{r + 1} {r + 1} 1.5" for r in range(50_000)]
+    for lineno, bad in ((40_000, "60000 1 1.0"), (30_000, "0 5 1.0"), (45_000, "7 7 x1")):
+        t = list(big)
+        t[lineno] = bad
+        assert not H.MMtoCSR(_write(tmp_path, "\n".join(t) + "\n", "bad.mtx")), bad
+    assert not H.MMtoCSR(_write(tmp_path, "\n".join(big[:-1]) + "\n", "short.mtx"))
+    assert not H.MMtoCSR(_write(tmp_path, "\n".join(big + ["3 4 1.0"]) + "\n", "long.mtx"))
+
+
+def test_structured_generators_have_the_published_shapes(tmp_path):
+    """spmvSynthWriteMtx: the three stand-ins for the matrices of the reference's report at reduced size,
+    written as .mtx and read back by the loader: rows / longest row / locality as stated, columns ascending and distinct,
+    values reproducible from (seed, row, column)."""
+    def gen(kind, p0, p1, p2, name):
+        Mv, NZv, mx = C.c_ulong(), C.c_ulong(), C.c_ulong()
+        path = str(tmp_path / name).encode()
+        assert H.spmvSynthWriteMtx(path, kind, p0, p1, p2, 77, C.byref(Mv), C.byref(NZv), C.byref(mx)) == 0
+        m = H.MMtoCSR(path)
+        assert m
+        c = m.contents
+        assert (c.M, c.N, c.NZ) == (Mv.value, Mv.value, NZv.value)
+        irp, ja, as_ = _arr(c.IRP, c.M + 1, np.int64), _arr(c.JA, c.NZ, np.int64), _arr(c.AS, c.NZ, np.float64)
+        lens = np.diff(irp)
+        assert lens.max() == mx.value
+        rows = np.repeat(np.arange(c.M), lens)
+        inner = np.ones(c.NZ, dtype=bool)
+        inner[irp[1:-1][irp[1:-1] < c.NZ]] = False
+        assert np.all(np.diff(ja)[inner[1:]] > 0)               # ascending, distinct inside every row
+        for i in (0, c.NZ // 3, c.NZ - 1):
+            assert as_[i] == H.spmvSynthStructuredValue(77, int(rows[i]), int(ja[i])) and as_[i] != 0
+        H.freeSpmat(m)
+        return lens, np.abs(ja - rows)
+    lens, dist = gen(0, 40, 20, 10, "stencil.mtx")              # 3-D stencil, 18 neighbours
+    assert lens.max() == 18 and lens.min() == 6 and lens.mean() > 14 and dist.max() == 40 * 20 + 40
+    lens, dist = gen(1, 200_000, 0, 0, "road.mtx")              # road network: short rows, near-diagonal columns
+    assert lens.max() <= 9 and 1.9 < lens.mean() < 2.4 and np.median(dist) <= 2 and lens.min() >= 1
+    lens, dist = gen(2, 36417, 24, 0, "block.mtx")              # dense blocks along the diagonal
+    assert 150 < lens.max() <= 204 and 100 < lens.mean() < 140
+    assert H.spmvSynthWriteMtx(b"/nonexistent/dir/x.mtx", 0, 4, 4, 4, 1, None, None, None) != 0
+    assert H.spmvSynthWriteMtx(str(tmp_path / "k.mtx").encode(), 9, 4, 4, 4, 1, None, None, None) != 0
+
+
 def test_ell_size_guard():
     """parser.c:223-232: 2*M*maxRow > 6<<27 entries is refused (BASELINE config 4 on the unclipped matrix)."""
     M = 1 << 20
