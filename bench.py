@@ -185,6 +185,7 @@ def format_info(api, dm, launcher):
     if launcher == "hipSpMVTilesCSR":
         i = api.tiles_info(dm)
         return {"extra_device_bytes": int(i.bytes), "format_build_ms": float(i.buildMs), "format_build_alloc_ms": float(getattr(i, "allocMs", 0.0)),
+                "format_build_peak_temporary_bytes": int(i.tempBytes), "format_build_peak_temporary_bytes_per_nnz": float(i.tempBytes) / max(int(dm.nnz), 1),
                 "bins": int(i.nBins), "rows_per_bin": int(i.rowsPerBin),
                 "phase1_work_item_entries": int(i.chunk), "product_workspace_bytes": int(dm.nnz) * 8}
     if launcher == "hipSpMVStripesCSR":
@@ -244,6 +245,8 @@ def measure_single(api, synth, torch, w, launcher, steps, warmup, candidates=Non
         "algorithmic_bytes": bytes_alg,
     })
     res.update(format_info(api, dm, launcher))
+    if res.get("format_build_ms"):
+        res["spmvs_to_amortise_format_build"] = res["format_build_ms"] / max(k_avg, 1e-9)
     if launcher == "hipSpMVRowsCSR" and _ROWS_VARIANT[0] == 2:
         nm = api.lib.spmvHipAutoChoiceRows(C.byref(dm.handle), None)
         res["launcher_resolved_to"] = nm.decode() if nm else None
@@ -977,6 +980,8 @@ def run_single(args, api, synth, torch, w):
                      "kernel_ms_avg": res["kernel_ms_avg"], "kernel_ms_var": res["kernel_ms_var"],
                      "kernel_ms_phases": res.get("kernel_ms_phases"),
                      "format_build_ms": res.get("format_build_ms"), "format_build_alloc_ms": res.get("format_build_alloc_ms"),
+                     "format_build_peak_temporary_bytes_per_nnz": res.get("format_build_peak_temporary_bytes_per_nnz"),
+                     "spmvs_to_amortise_format_build": res.get("spmvs_to_amortise_format_build"),
                      "extra_device_bytes": res.get("extra_device_bytes")},
         "parity": res["parity"],
     }
@@ -1372,7 +1377,10 @@ def main():
     api.set_variant("hipSpMVWarpPerRowCSR", 1)
     set_rows_variant(api, 1)
     if args.variant >= 0 and args.launcher != "auto":
-        api.set_variant(args.launcher, args.variant)
+        if args.launcher == "hipSpMVRowsCSR":
+            set_rows_variant(api, args.variant)
+        else:
+            api.set_variant(args.launcher, args.variant)
     w = synth.WORKLOADS[args.workload]
     if args.scale != 1.0:
         w = synth.scaled(w, args.scale)

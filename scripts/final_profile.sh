@@ -1,8 +1,8 @@
 # Round summary run on the GPU box: GPU tests, default bench, kernel trace + PMC passes per workload -> gpurun_out/<round>c;
 # condensed afterwards (in the repo) by scripts/make_summary.py <round> into profiles/<round>_summary.md + profiles/traffic.json
-#   usage: bash scripts/final_profile.sh r02
+#   usage: bash scripts/final_profile.sh r03
 cd /tmp && export TMPDIR=/tmp
-RND=${1:-r02}
+RND=${1:-r03}
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/${RND}c; rm -rf $O; mkdir -p $O; cd $R
 sha256sum spmv_openmp_cuda_amd/lib/libspmvhip.so | cut -d' ' -f1 > $O/libspmvhip.sha256
 ( time timeout -k 10 900 python3 bench.py ) > $O/bench_default.json 2> $O/bench_default.err
@@ -26,4 +26,19 @@ prof c3_onepass tf --workload c3 --launcher hipSpMVWarpPerRowCSR
 prof c2_stripes tfw --workload c2 --launcher hipSpMVStripesCSR
 prof c2_sell tfw --workload c2 --launcher hipSpMVRowsSELL
 prof c3b tfw --workload c3b
+# the serial-order default of hipSpMVRowsCSR (deterministic two-phase / stripes forms)
+prof c5_serial tf --workload c5 --launcher hipSpMVRowsCSR --variant 2
+prof c3_serial tf --workload c3 --launcher hipSpMVRowsCSR --variant 2
+prof c2_serial tf --workload c2 --launcher hipSpMVRowsCSR --variant 2
+# the reference's kind of matrix: every CSR and ELL kernel on the 3-D stencil stand-in (and the road network)
+pstruct() {
+  tag=$1; shift
+  B="python3 bench.py --no-cpu-baseline --steps 10 --warmup 2 --only-structured $*"
+  timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/$tag/trace -- $B > $O/$tag.trace.log 2>&1
+  timeout -k 10 400 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/$tag/pmc_fetch -- $B > $O/$tag.pmc1.log 2>&1
+  timeout -k 10 400 rocprofv3 --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum --output-format csv -d $O/$tag/pmc_write -- $B > $O/$tag.pmc2.log 2>&1
+  echo "profiled $tag"
+}
+pstruct stencil stencil3d
+pstruct road road
 ls $O

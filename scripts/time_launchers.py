@@ -51,8 +51,8 @@ def main():
         api.set_variant("hipSpMVWarpPerRowCSR", 2)
         if suffix.isdigit():
             api.set_variant(name, int(suffix))
-        elif suffix == "det" and name == "hipSpMVStripesCSR":
-            api.build_stripes(dm, deterministic=True)
+        elif suffix in ("det", "det2") and name == "hipSpMVStripesCSR":
+            api.build_stripes(dm, deterministic=2 if suffix == "det2" else 1)
         elif suffix == "det" and name == "hipSpMVTilesCSR":
             api.build_tiles(dm, deterministic=True)
         elif suffix == "" and name == "hipSpMVStripesCSR" and api.stripes_info(dm).deterministic:

@@ -397,7 +397,7 @@ def tiles_info(dmat: DeviceMatrix) -> spmvTilesInfo:
 
 def build_stripes(dmat: DeviceMatrix, rowsPerBin=0, grid=0, spread=-1, wide=-1, deterministic=False):
     """spmvHipBuildStripesOpt: (re)build the stripes format of this handle with explicit options."""
-    o = spmvStripesOpts(int(rowsPerBin), int(grid), int(spread), int(wide), 1 if deterministic else 0)
+    o = spmvStripesOpts(int(rowsPerBin), int(grid), int(spread), int(wide), int(deterministic))
     _check(lib.spmvHipBuildStripesOpt(C.byref(dmat.handle), C.byref(o)), "spmvHipBuildStripesOpt")
 
 

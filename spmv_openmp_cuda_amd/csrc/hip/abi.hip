@@ -599,7 +599,8 @@ static int tilesForm(spmat* dMat, double* dX, double* dY, bool det, const char* 
     }
     uint32_t bins = 0, rowsPerBin = 0;
     tilesShape(d, &bins, &rowsPerBin);
-    Launch L(grid2d((uint64_t)((bins + 7) / 8) * 8, det ? 256 : 1024), dim3(det ? 256 : 1024));   // phase 2's shape (phase 1: one workgroup per slice piece)
+    const uint32_t p2t = tilesPhase2Threads(d);
+    Launch L(grid2d((uint64_t)((bins + 7) / 8) * 8, p2t), dim3(p2t));   // phase 2's shape (phase 1: one workgroup per slice piece)
     if (enqueueTiles(d, dX, dY, S.stream)) { ERR("%s: launch failed", who); return EXIT_FAILURE; }
     return L.finish(who);
 }

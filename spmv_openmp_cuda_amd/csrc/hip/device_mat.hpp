@@ -86,6 +86,7 @@ int  enqueueTilesReducePush(DevMat* d, double* y, int nExtra, double* const* ext
                             hipEvent_t evFork, hipEvent_t evJoin);
 int  tilesPushFailed(DevMat* d);
 void tilesShape(const DevMat* d, uint32_t* bins, uint32_t* rowsPerBin);
+uint32_t tilesPhase2Threads(const DevMat* d);                   // workgroup size of phase 2 for the active form
 uint64_t tilesBinRow(const DevMat* d, uint32_t bin);
 hipStream_t libraryStream();                                    // abi.hip: the stream set with spmvHipSetStream
 size_t tilesBytes(const DevMat* d);

@@ -69,7 +69,7 @@ struct StripeFormat {
     uint32_t  B = 0, R = 0;                         // bins, rows of the highest bin
     uint32_t  subs = 1;                             // column-ordered sub-streams per bin: 1, or SB_WAVES in the deterministic form
     uint64_t  nnz = 0, nSteps = 0;
-    bool      wide = false, det = false;
+    bool      wide = false, det = false, det2 = false;
     double*   val = nullptr;                        // [nSteps * 128] sub-stream-major, column order inside a sub-stream, each padded to whole steps
     uint32_t* cr = nullptr;                         // narrow: (column - stepBase) << 15 | local row;  wide: column
     uint16_t* lrowW = nullptr;                      // wide only: local row
@@ -191,7 +191,7 @@ __global__ __launch_bounds__(256) void sb_fill16_kernel(uint16_t* __restrict__ p
 // (Measured and settled in round 2, logs under profiles/r02_stripes_*: `nt` stream loads beat plain ones by 8 %; plain
 // gathers -- `nt` ones no longer allocate in L2, 2.3 ms; buffer / scalar-base address forms of the gather equal; the kernel
 // without its LDS adds is no faster, without its gathers it is the 12 B/nnz stream.)
-struct SbStream { dbl2 v[SB_DEPTH]; u32x2 c[SB_DEPTH]; u16x2 r[SB_DEPTH]; uint32_t base[SB_DEPTH]; uint32_t first; };
+struct SbStream { dbl2 v[SB_DEPTH]; u32x2 c[SB_DEPTH]; u16x2 r[SB_DEPTH]; uint32_t base[SB_DEPTH]; uint32_t first, tk; };
 struct SbGather { double x0[SB_DEPTH], x1[SB_DEPTH]; };
 
 // stream loads of the batch with ticket `t` (wavefront-uniform).  A sub-stream has nb batches of SB_DEPTH steps; ticket t
@@ -205,6 +205,7 @@ __device__ __forceinline__ void sb_stream(SbStream& s, uint32_t t, const SbBin b
                                           const uint16_t* __restrict__ lrowW, const uint32_t* __restrict__ stepBase) {
     const uint32_t s1 = bn.s1;
     const uint32_t rb = t + bn.off;
+    s.tk = t;
     s.first = t < bn.nb ? bn.s0 + (rb >= bn.nb ? rb - bn.nb : rb) * SB_DEPTH : s1;
 #pragma unroll
     for (int u = 0; u < SB_DEPTH; ++u) {
@@ -256,13 +257,14 @@ __device__ __forceinline__ uint32_t sb_ticket(uint32_t* ctr, uint32_t lane) {
 // workgroup in a tight pack gathers no faster, because the gather is bounded by the lines a CU's L1 can have in
 // flight to L2 (~0.27-0.38 lines per clock and CU here and in scripts/microbench_gather.hip), not by L2 misses.
 
-template <bool WIDE, bool DET>
+template <bool WIDE, int DET>
 __global__ __launch_bounds__(SB_THREADS) void sb_spmv_kernel(
     uint32_t B, const uint32_t* __restrict__ binRow, const uint32_t* __restrict__ subStep,
     const double* __restrict__ val, const uint32_t* __restrict__ cr, const uint16_t* __restrict__ lrowW,
     const uint32_t* __restrict__ stepBase, const double* __restrict__ x, double* __restrict__ y, uint32_t ldsRows, uint32_t spread) {
     extern __shared__ double yb[];                  // ldsRows doubles (rows of the highest bin), then the ticket counter
     uint32_t* ctr = reinterpret_cast<uint32_t*>(yb + ldsRows);
+    volatile uint32_t* turn = ctr + 1;               // DET == 2: the ticket whose batch may add to the bin now
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x / 64)), lane = threadIdx.x % 64;
     // persistent: one workgroup per CU walks the bins w, w + G, ... (its bin of y fills the LDS, so no second
     // workgroup could share the CU anyway, and a bin starts the moment the previous one is stored)
@@ -272,7 +274,7 @@ __global__ __launch_bounds__(SB_THREADS) void sb_spmv_kernel(
         SbGather g0, g1;
         SbBin bn;
         uint32_t mine = 3;                           // DET: this wavefront's next batch
-        if (DET) {                                   // this wavefront's own sub-stream, from its first batch on
+        if (DET == 1) {                              // this wavefront's own sub-stream, from its first batch on
             bn.s0 = subStep[bin * SB_WAVES + wave]; bn.s1 = subStep[bin * SB_WAVES + wave + 1];
             bn.off = 0;
         } else {
@@ -281,16 +283,16 @@ __global__ __launch_bounds__(SB_THREADS) void sb_spmv_kernel(
         bn.nb = (bn.s1 - bn.s0 + SB_DEPTH - 1) / SB_DEPTH;
         // where this workgroup starts its sweep: the (up to) 32 workgroups of an XCD -- workgroups are dealt round-robin
         // to the 8 XCDs -- are spread over `spread`/1024 of the sweep
-        if (!DET) bn.off = (uint32_t)(((uint64_t)((lin_block() / 8) % 32) * bn.nb * spread) >> 15);
+        bn.off = DET ? 0u : (uint32_t)(((uint64_t)((lin_block() / 8) % 32) * bn.nb * spread) >> 15);
         const uint32_t s1 = bn.s1;
         const bool any = s1 > bn.s0;                 // uniform per workgroup (default form) / per wavefront (deterministic form)
         if (any) {                                   // first three batches; moving before the bin is zeroed
-            sb_stream<WIDE>(a, DET ? 0u : wave, bn, lane, val, cr, lrowW, stepBase);
-            sb_stream<WIDE>(b, DET ? 1u : wave + SB_WAVES, bn, lane, val, cr, lrowW, stepBase);
-            sb_stream<WIDE>(c, DET ? 2u : wave + 2 * SB_WAVES, bn, lane, val, cr, lrowW, stepBase);
+            sb_stream<WIDE>(a, DET == 1 ? 0u : wave, bn, lane, val, cr, lrowW, stepBase);
+            sb_stream<WIDE>(b, DET == 1 ? 1u : wave + SB_WAVES, bn, lane, val, cr, lrowW, stepBase);
+            sb_stream<WIDE>(c, DET == 1 ? 2u : wave + 2 * SB_WAVES, bn, lane, val, cr, lrowW, stepBase);
         }
         for (uint32_t k = threadIdx.x; k < R; k += SB_THREADS) yb[k] = 0.0;
-        if (!DET && threadIdx.x == 0) *ctr = 3 * SB_WAVES;
+        if (DET != 1 && threadIdx.x == 0) { *ctr = 3 * SB_WAVES; *turn = 0; }
         __syncthreads();
         if (any) {
             sb_gather<WIDE>(g0, a, x);
@@ -298,8 +300,16 @@ __global__ __launch_bounds__(SB_THREADS) void sb_spmv_kernel(
 #define SB_STAGE(CUR, NXT, FAR, GC, GN)                                                                          \
             if (CUR.first >= s1) break;                                                                          \
             sb_gather<WIDE>(GN, NXT, x);                                                                         \
-            sb_stream<WIDE>(FAR, DET ? mine++ : sb_ticket(ctr, lane), bn, lane, val, cr, lrowW, stepBase);       \
-            sb_add<WIDE>(yb, CUR, GC, s1);
+            sb_stream<WIDE>(FAR, DET == 1 ? mine++ : sb_ticket(ctr, lane), bn, lane, val, cr, lrowW, stepBase);  \
+            if (DET == 2) {       /* batches add in ticket order: wait for the batch before this one */        \
+                while ((uint32_t)__builtin_amdgcn_readfirstlane((int)*turn) != CUR.tk) __builtin_amdgcn_s_sleep(1); \
+            }                                                                                                    \
+            sb_add<WIDE>(yb, CUR, GC, s1);                                                                       \
+            if (DET == 2) {       /* LDS operations of one wavefront execute in issue order: the hand-over follows the adds */ \
+                asm volatile("" ::: "memory");                                                                   \
+                if (lane == 0) *turn = CUR.tk + 1;                                                               \
+                asm volatile("" ::: "memory");                                                                   \
+            }
             for (;;) {
                 SB_STAGE(a, b, d, g0, g1)
                 SB_STAGE(b, c, a, g1, g0)
@@ -387,7 +397,7 @@ int fillFormat(StripeFormat* f, bool wide, uint64_t nnz, unsigned colBits, const
     return EXIT_SUCCESS;
 }
 
-template <bool WIDE, bool DET>
+template <bool WIDE, int DET>
 void launchSpmv(const StripeFormat* f, const double* x, double* y, hipStream_t stream) {
     hipLaunchKernelGGL((sb_spmv_kernel<WIDE, DET>), dim3(f->grid), dim3(SB_THREADS), (size_t)8 * f->R + 16, stream, f->B, f->binRow, f->subStep,
                        f->val, f->cr, f->lrowW, f->stepBase, x, y, f->R, f->spread);
@@ -466,7 +476,8 @@ int buildStripes(DevMat* d, const spmvStripesOpts* opts) {
     StripeFormat* f = new StripeFormat;
     f->opts = o;
     f->det = o.deterministic != 0;
-    f->subs = f->det ? SB_WAVES : 1;
+    f->det2 = o.deterministic == 2;
+    f->subs = f->det && !f->det2 ? SB_WAVES : 1;
     f->B = B; f->R = R; f->nnz = nnz;
     f->grid = std::min<uint32_t>(B, cus);
     f->spread = f->det ? 0u : o.spread >= 0 ? (uint32_t)o.spread : SB_SPREAD;
@@ -531,10 +542,12 @@ int buildStripes(DevMat* d, const spmvStripesOpts* opts) {
         wide = true;                                  // some step spans >= 2^17 columns: 32-bit columns + 16-bit rows
     }
     // (set at every build: the attribute belongs to the current device, and a process may drive several)
-    if (hipFuncSetAttribute((const void*)sb_spmv_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, SB_R_MAX * 8 + 16) ||
-        hipFuncSetAttribute((const void*)sb_spmv_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, SB_R_MAX * 8 + 16) ||
-        hipFuncSetAttribute((const void*)sb_spmv_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, SB_R_MAX * 8 + 16) ||
-        hipFuncSetAttribute((const void*)sb_spmv_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, SB_R_MAX * 8 + 16))
+    if (hipFuncSetAttribute((const void*)sb_spmv_kernel<false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, SB_R_MAX * 8 + 16) ||
+        hipFuncSetAttribute((const void*)sb_spmv_kernel<true, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, SB_R_MAX * 8 + 16) ||
+        hipFuncSetAttribute((const void*)sb_spmv_kernel<false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, SB_R_MAX * 8 + 16) ||
+        hipFuncSetAttribute((const void*)sb_spmv_kernel<true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, SB_R_MAX * 8 + 16) ||
+        hipFuncSetAttribute((const void*)sb_spmv_kernel<false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, SB_R_MAX * 8 + 16) ||
+        hipFuncSetAttribute((const void*)sb_spmv_kernel<true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, SB_R_MAX * 8 + 16))
         return fail("kernel attribute");
     const uint64_t cells = steps * SB_STEP;
     f->bytes = cells * (f->wide ? 14 : 12) + (f->wide ? 0 : steps * 4) + ((size_t)B + 1) * 4 + ((size_t)nGroups + 1) * 4;
@@ -556,8 +569,9 @@ int enqueueStripes(DevMat* d, const double* x, double* y, hipStream_t stream, di
     if (!f) return EXIT_FAILURE;
     if (grid) *grid = dim3(f->grid);
     if (block) *block = dim3(SB_THREADS);
-    if (f->wide) { if (f->det) launchSpmv<true, true>(f, x, y, stream); else launchSpmv<true, false>(f, x, y, stream); }
-    else         { if (f->det) launchSpmv<false, true>(f, x, y, stream); else launchSpmv<false, false>(f, x, y, stream); }
+    const int mode = f->det2 ? 2 : f->det ? 1 : 0;
+    if (f->wide) { if (mode == 2) launchSpmv<true, 2>(f, x, y, stream); else if (mode == 1) launchSpmv<true, 1>(f, x, y, stream); else launchSpmv<true, 0>(f, x, y, stream); }
+    else         { if (mode == 2) launchSpmv<false, 2>(f, x, y, stream); else if (mode == 1) launchSpmv<false, 1>(f, x, y, stream); else launchSpmv<false, 0>(f, x, y, stream); }
     return hipGetLastError() == hipSuccess ? EXIT_SUCCESS : EXIT_FAILURE;
 }
 

@@ -55,7 +55,10 @@ constexpr uint32_t PB_R_MAX   = 20000;             // rows per bin: <= 156 KiB o
 constexpr uint32_t PB_CUS_DEFAULT = 256;           // compute units when the device does not say (phase 2 keeps one workgroup per CU)
 constexpr uint32_t PB_CHUNK   = 1u << 17;           // entries of one slice handled by one phase-1 workgroup
 constexpr int      PB_THREADS = 1024;
-constexpr uint32_t PD_WAVES   = 4;                 // deterministic form: wavefronts of a phase-2 workgroup = sub-bins of a bin
+#ifndef SPMV_PD_WAVES
+#define SPMV_PD_WAVES 8
+#endif
+constexpr uint32_t PD_WAVES   = SPMV_PD_WAVES;     // deterministic form: wavefronts of a phase-2 workgroup = sub-bins of a bin
 constexpr int      PD_THREADS = PD_WAVES * 64;
 constexpr size_t   PB_RESIDENT_BYTES = 288ull << 20; // products up to this size stay in the 256 MiB Infinity Cache between the phases (c2, 244 MiB: 0.156 ms plain vs 0.176 ms nt stores)
 
@@ -86,7 +89,8 @@ struct TileFormat {
     double*   val = nullptr;                        // slice-major values
     uint16_t* lcol = nullptr;                       // slice-major: column - slice*PB_C
     uint16_t* lrow = nullptr;                       // BIN-major: row - bin*R
-    bool      det = false;                          // deterministic form: `bins` / B / binPos / waveTile describe SUB-bins (PD_WAVES per bin of the API)
+    bool      det = false;                          // deterministic form: `bins` / B / binPos describe SUB-bins (PD_WAVES per bin of the API)
+    uint32_t* pidx = nullptr;                       // deterministic form: BIN-major position -> slice-major position of its product
     size_t    tempBytes = 0;                        // peak of the temporaries of the build
     uint2*    tl = nullptr;                         // non-empty tiles in bin-major order: {first bin-major position,
                                                     // slice-major start - bin-major start (mod 2^32)}; sentinels follow
@@ -205,7 +209,7 @@ __global__ __launch_bounds__(256) void pb_list_kernel(uint32_t S, uint32_t B, ui
 __global__ __launch_bounds__(256) void pb_place_kernel(
     uint64_t nnz, const PbPay* __restrict__ spay, const uint32_t* __restrict__ skeys,
     uint32_t S, uint32_t B, BinMap bm, const uint32_t* __restrict__ tileStart, const uint32_t* __restrict__ bmStart,
-    double* __restrict__ val, uint16_t* __restrict__ lcol, uint16_t* __restrict__ lrow) {
+    double* __restrict__ val, uint16_t* __restrict__ lcol, uint16_t* __restrict__ lrow, uint32_t* __restrict__ pidx) {
     const uint64_t p = lin_block() * 256 + threadIdx.x;
     if (p >= nnz) return;
     const PbPay e = spay[p];
@@ -214,7 +218,9 @@ __global__ __launch_bounds__(256) void pb_place_kernel(
     val[p] = pb_value(e);
     lcol[p] = (uint16_t)(key & (PB_C - 1));
     const uint32_t within = (uint32_t)p - tileStart[(uint64_t)slice * B + bin];
-    lrow[bmStart[(uint64_t)bin * S + slice] + within] = (uint16_t)(e.row - bm.row0(bin));
+    const uint32_t at = bmStart[(uint64_t)bin * S + slice] + within;
+    lrow[at] = (uint16_t)(e.row - bm.row0(bin));
+    if (pidx) pidx[at] = (uint32_t)p;
 }
 
 __global__ __launch_bounds__(256) void pb_fill_kernel(uint32_t* p, uint64_t n, uint32_t v) {
@@ -488,17 +494,48 @@ __global__ __launch_bounds__(PB_THREADS) void pb_reduce_kernel(
 }
 
 // Deterministic form of phase 2.  A bin of the API is PD_WAVES consecutive SUB-bins; the format's tables (bins, binPos,
-// tile list, local rows) are built on the sub-bins, and wavefront w of the bin's workgroup walks sub-bin w from its first
-// entry to its last in bin-major order -- slice by slice, a tile sorted by (row, column) -- with plain ds_add_f64.  A row
-// therefore receives its products from ONE wavefront in ascending column order (lanes of one instruction that meet in a row
-// are served in lane order), which is the order of the serial oracle, whatever the scheduler does and however the rows were
-// cut into bins or shards.  Cost: 4 wavefronts per CU instead of 16 to keep the two streams in flight, and tiles a quarter as
-// long (c5: 20 instead of 80 entries).
+// local rows) are built on the sub-bins, and wavefront w of the bin's workgroup walks sub-bin w from its first entry to its
+// last in bin-major order -- slice by slice, a tile sorted by (row, column) -- with plain ds_add_f64.  A row therefore
+// receives its products from ONE wavefront in ascending column order (lanes of one instruction that meet in a row are served
+// in lane order), which is the order of the serial oracle, whatever the scheduler does and however the rows were cut into
+// bins or shards.
+// With a sub-bin per wavefront the tiles are PD_WAVES times shorter than a bin's (c5: 10 entries), and the scalar walk
+// through the tile table that serves the arrival-order kernel -- one dependent s_load per tile boundary -- becomes the
+// bottleneck (first version, 4 wavefronts: phase 2 of c5 8.7 ms against 3.0).  This form therefore stores, per bin-major
+// position, the slice-major position of its product (`pidx`, +4 B/nnz) and runs as a three-stage software pipeline like
+// the stripes kernel: stream (pidx, local row; non-temporal) two batches ahead, product gather one batch ahead (default
+// policy: neighbouring sub-bins read the same lines), LDS adds -- vmcnt counts in issue order, so a gather is only
+// waited for while younger stream loads are outstanding if those were issued after it.
+constexpr int PD_DEPTH = 8;                          // steps of 64 entries per batch
+struct PdStream { uint32_t idx[PD_DEPTH]; uint16_t row[PD_DEPTH]; uint32_t first; };
+struct PdGather { double p[PD_DEPTH]; };
+
+__device__ __forceinline__ void pd_stream(PdStream& s, uint32_t vb, uint32_t we, uint32_t lane, const uint32_t* __restrict__ pidx,
+                                          const uint16_t* __restrict__ lrow) {
+    s.first = vb;
+#pragma unroll
+    for (int u = 0; u < PD_DEPTH; ++u) {
+        const uint32_t v = vb + 64u * u + lane, vc = min(v, we - 1u);       // clamped, not branched: vmcnt stays exact
+        s.idx[u] = __builtin_nontemporal_load(pidx + vc);
+        const uint16_t r = __builtin_nontemporal_load(lrow + vc);
+        s.row[u] = v < we ? r : P2_NONE;
+    }
+}
+__device__ __forceinline__ void pd_gather(PdGather& g, const PdStream& s, const double* __restrict__ prod) {
+#pragma unroll
+    for (int u = 0; u < PD_DEPTH; ++u) g.p[u] = prod[s.idx[u]];
+}
+__device__ __forceinline__ void pd_add(double* yw, const PdStream& s, const PdGather& g) {
+#pragma unroll
+    for (int u = 0; u < PD_DEPTH; ++u)
+        if (s.row[u] != P2_NONE) atomicAdd(&yw[s.row[u]], g.p[u]);
+}
+
 template <int MODE>
 __global__ __launch_bounds__(PD_THREADS) void pb_reduce_det_kernel(
     BinMap bm, uint32_t nSub, uint32_t binBegin, uint32_t binEnd, uint64_t M, const uint32_t* __restrict__ binPos,
-    const uint32_t* __restrict__ subTile, const uint2* __restrict__ tl, const double* __restrict__ prod,
-    const uint16_t* __restrict__ lrow, double* __restrict__ y, TileDst extra, TileSignal sig) {
+    const uint32_t* __restrict__ pidx, const double* __restrict__ prod, const uint16_t* __restrict__ lrow,
+    double* __restrict__ y, TileDst extra, TileSignal sig) {
     extern __shared__ double yb[];                  // PD_WAVES * (rows of a sub-bin) doubles
     const uint64_t bin = binBegin + lin_block();
     if (bin >= binEnd) return;
@@ -509,29 +546,34 @@ __global__ __launch_bounds__(PD_THREADS) void pb_reduce_det_kernel(
     uint32_t wb = 0, we = 0;
     if (sb < nSub) { wb = binPos[sb]; we = binPos[sb + 1]; }
     const bool busy = we > wb;                       // uniform per wavefront
-    P2Cursor c;
-    P2Regs a, b;
-    if (busy) {
-        c.k = subTile[sb];
-        c.delta = tl[c.k].y;
-        c.n1 = tl[c.k + 1];
-        c.n2 = tl[c.k + 2];
-        p2_fetch(a, c, wb, we, lane, tl, prod, lrow);
+    constexpr uint32_t BATCH = PD_DEPTH * 64;
+    PdStream a, b, c, d;
+    PdGather g0, g1;
+    if (busy) {                                      // first three batches: moving before the bin is zeroed
+        pd_stream(a, wb, we, lane, pidx, lrow);
+        pd_stream(b, wb + BATCH, we, lane, pidx, lrow);
+        pd_stream(c, wb + 2 * BATCH, we, lane, pidx, lrow);
     }
     const uint32_t R = PD_WAVES * Rs;
     for (uint32_t k = threadIdx.x; k < R; k += PD_THREADS) yb[k] = 0.0;
     __syncthreads();
     if (busy) {
-        for (uint32_t v = wb; v < we; v += 2 * P2_DEPTH * 64) {
-            p2_fetch(b, c, v + P2_DEPTH * 64, we, lane, tl, prod, lrow);
-#pragma unroll
-            for (int u = 0; u < P2_DEPTH; ++u)
-                if (a.rv[u] != P2_NONE) atomicAdd(&yw[a.rv[u]], a.pv[u]);
-            p2_fetch(a, c, v + 2 * P2_DEPTH * 64, we, lane, tl, prod, lrow);
-#pragma unroll
-            for (int u = 0; u < P2_DEPTH; ++u)
-                if (b.rv[u] != P2_NONE) atomicAdd(&yw[b.rv[u]], b.pv[u]);
+        pd_gather(g0, a, prod);
+        uint32_t next = wb + 3 * BATCH;
+        // one stage: CUR is added, NXT gathered, FAR (the set CUR's predecessor freed) streamed
+#define PD_STAGE(CUR, NXT, FAR, GC, GN)                   \
+        if (CUR.first >= we) break;                       \
+        pd_gather(GN, NXT, prod);                         \
+        pd_stream(FAR, next, we, lane, pidx, lrow);       \
+        next += BATCH;                                    \
+        pd_add(yw, CUR, GC);
+        for (;;) {
+            PD_STAGE(a, b, d, g0, g1)
+            PD_STAGE(b, c, a, g1, g0)
+            PD_STAGE(c, d, b, g0, g1)
+            PD_STAGE(d, a, c, g1, g0)
         }
+#undef PD_STAGE
     }
     __syncthreads();
     p2_finish<MODE, PD_THREADS>(yb, R, bm.row0((uint32_t)bin * PD_WAVES), M, y, extra, sig, (uint32_t)bin);
@@ -725,7 +767,7 @@ uint64_t tilesBinRow(const DevMat* d, uint32_t bin) {
 
 void freeTiles(TileFormat* t) {
     if (!t) return;
-    (void)hipFree(t->slab); (void)hipFree(t->tl);
+    (void)hipFree(t->slab); (void)hipFree(t->tl); (void)hipFree(t->pidx);
     (void)hipFree(t->binPos); (void)hipFree(t->waveTile); (void)hipFree(t->work); (void)hipFree(t->ready);
     delete t;
 }
@@ -834,7 +876,8 @@ int buildTiles(DevMat* d, const spmvTilesOpts* opts) {
     if (hipMalloc(&t->slab, slabBytes) || payB.alloc(nnz * sizeof(PbPay)) || tileStart.alloc((nTiles + 2) * 4))
         return fail("format / temporary allocation (12 B per entry of temporaries while the format is built)");
     double* const prodBuf = prodWorkspace(nnz, true);
-    if (!prodBuf || hipMalloc(&t->binPos, ((size_t)t->B + 1) * 4) || hipMalloc(&t->waveTile, (size_t)t->B * (t->det ? 1 : P2_WAVES) * 4))
+    if (!prodBuf || hipMalloc(&t->binPos, ((size_t)t->B + 1) * 4) || hipMalloc(&t->waveTile, (size_t)t->B * (t->det ? 1 : P2_WAVES) * 4) ||
+        (t->det && hipMalloc(&t->pidx, nnz * 4)))
         return fail("format allocation");
     t->allocMs = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - allocT0).count();
     t->val  = static_cast<double*>(t->slab);
@@ -898,7 +941,7 @@ int buildTiles(DevMat* d, const spmvTilesOpts* opts) {
                            tileStart.as<uint32_t>(), lens.as<uint32_t>(), bmStart.as<uint32_t>(), listIdx.as<uint32_t>(), t->nList,
                            t->tl, t->binPos, binTile.as<uint32_t>());
         hipLaunchKernelGGL(pb_place_kernel, grid2d((nnz + 255) / 256, 256), dim3(256), 0, nullptr, nnz, spay, skeys, t->S, t->B, t->bins,
-                           tileStart.as<uint32_t>(), bmStart.as<uint32_t>(), t->val, t->lcol, t->lrow);
+                           tileStart.as<uint32_t>(), bmStart.as<uint32_t>(), t->val, t->lcol, t->lrow, t->pidx);
         if (t->det) {
             // every wavefront walks a whole sub-bin: its cursor starts at the sub-bin's first tile
             PB_TRY(hipMemcpyAsync(t->waveTile, binTile.p, (size_t)t->B * 4, hipMemcpyDeviceToDevice, nullptr));
@@ -916,7 +959,7 @@ int buildTiles(DevMat* d, const spmvTilesOpts* opts) {
         PB_TRY(hipGetLastError());
         PB_TRY(hipDeviceSynchronize());
     }
-    t->bytes = slabBytes + ((size_t)t->nList + TL_PAD) * 8 + ((size_t)t->B + 1) * 4 + (size_t)t->B * (t->det ? 1 : P2_WAVES) * 4;
+    t->bytes = slabBytes + (t->det ? nnz * 4 : 0) + ((size_t)t->nList + TL_PAD) * 8 + ((size_t)t->B + 1) * 4 + (size_t)t->B * (t->det ? 1 : P2_WAVES) * 4;
 
     // phase-1 work list from the slice boundaries (tileStart[s*B])
     std::vector<uint32_t> sliceStart(t->S + 1);
@@ -1028,6 +1071,8 @@ void tilesInfo(const DevMat* d, spmvTilesInfo* out) {
     out->tempBytes = t->tempBytes; out->deterministic = t->det ? 1 : 0;
 }
 
+uint32_t tilesPhase2Threads(const DevMat* d) { return d->tiles && d->tiles->det ? (uint32_t)PD_THREADS : (uint32_t)PB_THREADS; }
+
 void tilesShape(const DevMat* d, uint32_t* bins, uint32_t* rowsPerBin) {
     *bins = d->tiles ? d->tiles->apiBins() : 0;
     *rowsPerBin = d->tiles ? d->tiles->apiRows() : 0;
@@ -1067,10 +1112,10 @@ int enqueueTilesReduce(DevMat* d, uint32_t binBegin, uint32_t binEnd, double* y,
         const size_t lds = (size_t)8 * t->apiRows();
         if (nExtra)
             hipLaunchKernelGGL(pb_reduce_det_kernel<1>, grid, dim3(PD_THREADS), lds, stream, t->bins, t->B, binBegin, binEnd, d->M, t->binPos,
-                               t->waveTile, t->tl, prod, t->lrow, y, dst, none);
+                               t->pidx, prod, t->lrow, y, dst, none);
         else
             hipLaunchKernelGGL(pb_reduce_det_kernel<0>, grid, dim3(PD_THREADS), lds, stream, t->bins, t->B, binBegin, binEnd, d->M, t->binPos,
-                               t->waveTile, t->tl, prod, t->lrow, y, dst, none);
+                               t->pidx, prod, t->lrow, y, dst, none);
         return hipGetLastError() == hipSuccess ? EXIT_SUCCESS : EXIT_FAILURE;
     }
     if (nExtra)
@@ -1107,7 +1152,7 @@ int enqueueTilesReducePush(DevMat* d, double* y, int nExtra, double* const* extr
                        epoch, y, dst, t->pushFail);
     if (t->det)
         hipLaunchKernelGGL(pb_reduce_det_kernel<2>, grid2d((uint64_t)((nb + 7) / 8) * 8, PB_THREADS), dim3(PD_THREADS), (size_t)8 * t->apiRows(), stream,
-                           t->bins, t->B, 0u, nb, d->M, t->binPos, t->waveTile, t->tl, prod, t->lrow, y, TileDst{}, sig);
+                           t->bins, t->B, 0u, nb, d->M, t->binPos, t->pidx, prod, t->lrow, y, TileDst{}, sig);
     else
         hipLaunchKernelGGL(pb_reduce_kernel<2>, grid2d((uint64_t)((t->B + 7) / 8) * 8, PB_THREADS), dim3(PB_THREADS), (size_t)8 * t->R, stream,
                            t->bins, 0u, t->B, d->M, t->binPos, t->waveTile, t->tl, prod, t->lrow, y, TileDst{}, sig);
