@@ -621,7 +621,7 @@ def measure_block(api, synth, torch, w, launcher, steps, warmup, candidates=None
     if res["auto_candidates_ms"] and hasattr(api.lib, "hipSpMVAutoCSR"):
         # what a caller of the C-ABI's own selector gets for this matrix (hipSpMVAutoCSR measures inside the library at
         # its first call; SELL is not among its candidates) -- after the timed launcher's y has been checked, checked itself
-        ms3 = (C.c_double * 3)()
+        ms3 = (C.c_double * 4)()
         y_t.fill_(float("nan"))
         if api.lib.hipSpMVAutoCSR(C.byref(ctx["dm"].handle), ctx["x"].data_ptr(), api.CONFIG(), y_t.data_ptr()) == 0:
             torch.cuda.synchronize()
@@ -640,12 +640,13 @@ def measure_block(api, synth, torch, w, launcher, steps, warmup, candidates=None
             y_t.fill_(float("nan"))
             if api.lib.hipSpMVRowsCSR(C.byref(ctx["dm"].handle), ctx["x"].data_ptr(), api.CONFIG(), y_t.data_ptr()) == 0:
                 torch.cuda.synchronize()
-                ms3 = (C.c_double * 3)()
+                ms3 = (C.c_double * 4)()
                 name = api.lib.spmvHipAutoChoiceRows(C.byref(ctx["dm"].handle), ms3)
                 par3 = win.check(lambda a, b: y_t[a:b].cpu().numpy(), bitwise=True)
                 res["library_serial_order_choice"] = {
                     "launcher": name.decode() if name else None, "bit_identical_to_serial_oracle": bool(par3["ok"]),
-                    "ms": dict(zip(("hipSpMVRowsCSR(LDS-stream)", "hipSpMVTilesCSR(deterministic)", "hipSpMVStripesCSR(deterministic)"), [float(v) for v in ms3]))}
+                    "ms": dict(zip(("hipSpMVRowsCSR(LDS-stream)", "hipSpMVTilesCSR(deterministic)", "hipSpMVStripesCSR(owner wavefronts)",
+                                    "hipSpMVStripesCSR(ordered tickets)"), [float(v) for v in ms3]))}
                 if not par3["ok"]:
                     raise SystemExit(f"PARITY FAILURE on {w.name} [hipSpMVRowsCSR variant 2 -> {name}]: {par3}")
         finally:

@@ -148,11 +148,16 @@ int    spmvHipStripesShape(spmat* dMat, unsigned* nBins, unsigned* rowsPerBin, i
  *   spread         -1 or 0..1024: 1/1024ths of a bin over which the column sweeps of one XCD's workgroups start
  *                  (default 6; ignored by the deterministic form).
  *   wide           1: force the 14 B/nnz encoding with 32-bit columns; 0 / -1: only when a step spans >= 2^17 columns.
- *   deterministic  1: every row is added by ONE wavefront in ascending column order (local row mod 4 owns it), so the
- *                  result is the same bits in every run, on any number of row shards, and -- the products being rounded
- *                  before they are added -- the bits of the serial oracle (sgemvSerial, src/SpMV_CSR_OMP.c:229-250) when
- *                  the columns of every row ascend, as the reference's loader guarantees (src/lib/parser.c:195-202).
- *                  Costs time: a gather covers neighbours of a quarter of the bin's entries. */
+ *   deterministic  1 or 2: a row's products are added in ascending column order, so the result is the same bits in every run,
+ *                  on any number of row shards, and -- the products being rounded before they are added -- the bits of the
+ *                  serial oracle (sgemvSerial, src/SpMV_CSR_OMP.c:229-250) when the columns of every row ascend, as the
+ *                  reference's loader guarantees (src/lib/parser.c:195-202).  1 = "owner wavefronts": every row is added by
+ *                  ONE wavefront (local row mod 4 owns it) walking its own column-ordered sub-stream -- a layout of its own;
+ *                  nearly free on matrices with column locality, 1.5-2x on uniformly spread columns (a gather covers
+ *                  neighbours of a quarter of the bin's entries).  2 = "ordered tickets": the layout and the shared stream
+ *                  of the arrival-order kernel (options 0 and 2 build the same format), but the batches add in ticket order,
+ *                  handed over through an LDS word: 1.2x on uniformly spread columns, 1.5x where many lanes of an
+ *                  instruction meet in a row (narrow bands).  hipSpMVRowsCSR's default measures both. */
 typedef struct { unsigned rowsPerBin; unsigned grid; int spread; int wide; int deterministic; } spmvStripesOpts;
 int spmvHipBuildStripesOpt(spmat* dMat, const spmvStripesOpts* opts);
 typedef struct {
@@ -171,12 +176,13 @@ int spmvHipStripesInfo(spmat* dMat, spmvStripesInfo* info);   /* zeros when the 
  * format + 3 timed ones; each leaves the complete y), keeps the fastest and frees the private formats of the others;
  * it synchronises the stream even after spmvHipSetSync(0).  Later calls go straight to the chosen launcher.
  * spmvHipAutoChoice: its name (NULL before the first call) and, if msPerCandidate != NULL, the three measured times in
- * ms in the order above (0 = not eligible / not tried).  Arrival-order sums when a format kernel wins. */
+ * ms in the order above (0 = not eligible / not tried; room for FOUR doubles, the fourth stays 0).  Arrival-order sums
+ * when a format kernel wins. */
 SPMV_HIP hipSpMVAutoCSR;
 const char* spmvHipAutoChoice(spmat* dMat, double* msPerCandidate);
 /* The same report for the selection hipSpMVRowsCSR (variant 2) makes among the SERIAL-ORDER kernels: "hipSpMVRowsCSR" (the
- * LDS-stream kernel, one thread per row), "hipSpMVTilesCSR(deterministic)", "hipSpMVStripesCSR(deterministic)"; the three
- * times in that order.  Whichever is chosen, y is the bits of sgemvSerial. */
+ * LDS-stream kernel, one thread per row), "hipSpMVTilesCSR(deterministic)", "hipSpMVStripesCSR(owner wavefronts)",
+ * "hipSpMVStripesCSR(ordered tickets)"; FOUR times in that order.  Whichever is chosen, y is the bits of sgemvSerial. */
 const char* spmvHipAutoChoiceRows(spmat* dMat, double* msPerCandidate);
 
 /* SELL-C-sigma (C = 64 rows per slice = one wavefront, rows sorted by length inside 16 Ki-row

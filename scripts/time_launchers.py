@@ -47,7 +47,7 @@ def main():
     for spec in a.launchers:
         name, _, suffix = modes.get(spec, spec).partition(":")
         fn = api.SPMV_LAUNCHERS[name]
-        api.set_variant("hipSpMVRowsCSR", 1)
+        api.set_variant("hipSpMVRowsCSR", 2)                 # the library defaults
         api.set_variant("hipSpMVWarpPerRowCSR", 2)
         if suffix.isdigit():
             api.set_variant(name, int(suffix))
@@ -55,7 +55,7 @@ def main():
             api.build_stripes(dm, deterministic=2 if suffix == "det2" else 1)
         elif suffix == "det" and name == "hipSpMVTilesCSR":
             api.build_tiles(dm, deterministic=True)
-        elif suffix == "" and name == "hipSpMVStripesCSR" and api.stripes_info(dm).deterministic:
+        elif suffix == "" and name == "hipSpMVStripesCSR" and api.stripes_info(dm).nBins and api.stripes_info(dm).deterministic:
             api.build_stripes(dm)
         elif suffix == "" and name == "hipSpMVTilesCSR" and api.tiles_info(dm).nBins and getattr(api.tiles_info(dm), "deterministic", 0):
             api.build_tiles(dm)
@@ -68,9 +68,10 @@ def main():
         if name == "hipSpMVStripesCSR":
             i = api.stripes_info(dm)
             extra = f" bins={i.nBins} rows/bin<={i.rowsPerBin} wide={i.wide} det={i.deterministic} build={i.buildMs:.1f}ms"
-        if name in ("hipSpMVWarpPerRowCSR", "hipSpMVAutoCSR"):
-            pick = api.lib.spmvHipAutoChoice(C.byref(dm.handle), None)
-            extra = f" pick={pick.decode() if pick else None}"
+        if name in ("hipSpMVWarpPerRowCSR", "hipSpMVAutoCSR", "hipSpMVRowsCSR"):
+            ms4 = (C.c_double * 4)()
+            pick = (api.lib.spmvHipAutoChoiceRows if name == "hipSpMVRowsCSR" else api.lib.spmvHipAutoChoice)(C.byref(dm.handle), ms4)
+            extra = f" pick={pick.decode() if pick else None} candidates_ms={[round(v, 4) for v in ms4]}"
         if a.check:
             if windows is None:
                 windows = bench.OracleWindows(synth, w, irp, x_host, lens)

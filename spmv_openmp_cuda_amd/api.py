@@ -385,7 +385,7 @@ def spmv(launcher: str, dmat: DeviceMatrix, dx: DeviceVector, dy: DeviceVector, 
 
 def build_tiles(dmat: DeviceMatrix, rowsPerBin=0, taper=False, ntStore=-1, chunk=0, deterministic=False):
     """spmvHipBuildTilesOpt: (re)build the two-phase format of this handle with explicit options."""
-    o = spmvTilesOpts(int(rowsPerBin), 1 if taper else 0, int(ntStore), int(chunk), 1 if deterministic else 0)
+    o = spmvTilesOpts(int(rowsPerBin), 1 if taper else 0, int(ntStore), int(chunk), 1 if deterministic else 0)     # (no second form for this format)
     _check(lib.spmvHipBuildTilesOpt(C.byref(dmat.handle), C.byref(o)), "spmvHipBuildTilesOpt")
 
 

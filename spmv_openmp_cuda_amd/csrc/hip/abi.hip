@@ -604,26 +604,28 @@ static int tilesForm(spmat* dMat, double* dX, double* dY, bool det, const char* 
     if (enqueueTiles(d, dX, dY, S.stream)) { ERR("%s: launch failed", who); return EXIT_FAILURE; }
     return L.finish(who);
 }
-static int stripesForm(spmat* dMat, double* dX, double* dY, bool det, const char* who) {
+// mode: 0 arrival order, 1 owner wavefronts (its own layout), 2 ordered tickets (the layout of mode 0)
+static int stripesForm(spmat* dMat, double* dX, double* dY, int mode, const char* who) {
     DevMat* d = descOf(dMat, who);
     if (!d) return EXIT_FAILURE;
     if (d->kind != Kind::CSR) { ERR("%s: handle is not CSR", who); return EXIT_FAILURE; }
     if (d->M == 0 || d->NZ == 0) return nothingToLaunch(d, dY);         // nothing to sweep: y = 0
-    useStripes(d, det);
+    useStripes(d, mode == 1);
     if (!d->stripes) {
         const spmvStripesOpts o{0, 0, -1, -1, 1};
-        if (buildStripes(d, det ? &o : nullptr)) return EXIT_FAILURE;
+        if (buildStripes(d, mode == 1 ? &o : nullptr)) return EXIT_FAILURE;
     }
     Launch L(dim3(1), dim3(1));
     dim3 grid, block;
-    if (enqueueStripes(d, dX, dY, S.stream, &grid, &block)) { ERR("%s: launch failed", who); return EXIT_FAILURE; }
+    if (enqueueStripes(d, dX, dY, S.stream, mode, &grid, &block)) { ERR("%s: launch failed", who); return EXIT_FAILURE; }
     L.shape(grid, block);                            // the persistent grid that ran: min(bins, CUs) workgroups of 256 threads
     return L.finish(who);
 }
 static int tilesArrival(spmat* m, double* x, CONFIG, double* y)   { return tilesForm(m, x, y, false, "hipSpMVTilesCSR"); }
 static int tilesSerial(spmat* m, double* x, CONFIG, double* y)    { return tilesForm(m, x, y, true, "hipSpMVTilesCSR (deterministic)"); }
-static int stripesArrival(spmat* m, double* x, CONFIG, double* y) { return stripesForm(m, x, y, false, "hipSpMVStripesCSR"); }
-static int stripesSerial(spmat* m, double* x, CONFIG, double* y)  { return stripesForm(m, x, y, true, "hipSpMVStripesCSR (deterministic)"); }
+static int stripesArrival(spmat* m, double* x, CONFIG, double* y) { return stripesForm(m, x, y, 0, "hipSpMVStripesCSR"); }
+static int stripesOwner(spmat* m, double* x, CONFIG, double* y)   { return stripesForm(m, x, y, 1, "hipSpMVStripesCSR (deterministic: owner wavefronts)"); }
+static int stripesOrdered(spmat* m, double* x, CONFIG, double* y) { return stripesForm(m, x, y, 2, "hipSpMVStripesCSR (deterministic: ordered tickets)"); }
 
 static int autoRun(spmat* dMat, double* dX, CONFIG cfg, double* dY, int serial, const char* who);
 
@@ -712,17 +714,17 @@ int spmvHipBuildStripes(spmat* dMat) {
     DevMat* d = descOf(dMat, "spmvHipBuildStripes");
     if (!d) return EXIT_FAILURE;
     if (d->kind != Kind::CSR) { ERR("spmvHipBuildStripes: handle is not CSR"); return EXIT_FAILURE; }
-    useStripes(d, d->stripesPref);
+    useStripes(d, d->stripesPref == 1);
     if (d->stripes) return EXIT_SUCCESS;
     const spmvStripesOpts o{0, 0, -1, -1, 1};
-    return buildStripes(d, d->stripesPref ? &o : nullptr);
+    return buildStripes(d, d->stripesPref == 1 ? &o : nullptr);
 }
 int spmvHipBuildStripesOpt(spmat* dMat, const spmvStripesOpts* opts) {
     DevMat* d = descOf(dMat, "spmvHipBuildStripesOpt");
     if (!d || !opts) return EXIT_FAILURE;
     if (d->kind != Kind::CSR || d->M == 0 || d->NZ == 0) { ERR("spmvHipBuildStripesOpt: needs a non-empty CSR handle"); return EXIT_FAILURE; }
     if (buildStripes(d, opts)) return EXIT_FAILURE;
-    d->stripesPref = opts->deterministic != 0;       // what hipSpMVStripesCSR and the queries use from now on
+    d->stripesPref = opts->deterministic;            // what hipSpMVStripesCSR and the queries use from now on
     return EXIT_SUCCESS;
 }
 size_t spmvHipStripesBytes(spmat* dMat) {
@@ -732,8 +734,9 @@ size_t spmvHipStripesBytes(spmat* dMat) {
 int spmvHipStripesInfo(spmat* dMat, spmvStripesInfo* info) {
     DevMat* d = descOf(dMat, "spmvHipStripesInfo");
     if (!d || !info) return EXIT_FAILURE;
-    useStripes(d, d->stripesPref);
+    useStripes(d, d->stripesPref == 1);
     stripesInfo(d, info);
+    if (info->nBins && d->stripesPref == 2) info->deterministic = 2;     // the shared-stream layout, launched in ticket order
     return EXIT_SUCCESS;
 }
 int spmvHipStripesShape(spmat* dMat, unsigned* nBins, unsigned* rowsPerBin, int* wide, double* buildMs) {
@@ -761,21 +764,27 @@ int spmvHipStripesShape(spmat* dMat, unsigned* nBins, unsigned* rowsPerBin, int*
 // stays, the formats of the others are released, and the chosen launcher runs once more so that y is its own.  The
 // first call is a normal -- slow -- SpMV and synchronises the stream even in enqueue-only mode.
 namespace {
-constexpr int      AUTO_N = 3, AUTO_REPS = 3;
+constexpr int      AUTO_N = 4, AUTO_REPS = 3;
 constexpr uint64_t AUTO_MIN_NNZ = 1ull << 18;        // below this a launch is mostly latency: no private format pays
 constexpr uint64_t AUTO_STRIPES_X_BYTES = 256ull << 20;   // the stripes kernel re-reads x once per XCD and round of bins
 struct AutoCand { const char* name; SPMV_HIP* fn; };
 const AutoCand AUTO_CAND[2][AUTO_N] = {
-    {{"hipSpMVWarpPerRowCSR", &streamReduce}, {"hipSpMVTilesCSR", &tilesArrival}, {"hipSpMVStripesCSR", &stripesArrival}},
-    {{"hipSpMVRowsCSR", &streamSerial}, {"hipSpMVTilesCSR(deterministic)", &tilesSerial}, {"hipSpMVStripesCSR(deterministic)", &stripesSerial}}};
+    {{"hipSpMVWarpPerRowCSR", &streamReduce}, {"hipSpMVTilesCSR", &tilesArrival}, {"hipSpMVStripesCSR", &stripesArrival}, {nullptr, nullptr}},
+    {{"hipSpMVRowsCSR", &streamSerial}, {"hipSpMVTilesCSR(deterministic)", &tilesSerial}, {"hipSpMVStripesCSR(owner wavefronts)", &stripesOwner},
+     {"hipSpMVStripesCSR(ordered tickets)", &stripesOrdered}}};
 
 int autoSelect(spmat* dMat, DevMat* d, int serial, double* dX, CONFIG cfg, double* dY) {
     const bool fmtOk = d->NZ >= AUTO_MIN_NNZ && d->NZ < IRP32_LIMIT;
-    const bool eligible[AUTO_N] = {true, fmtOk, fmtOk && d->N * 8 <= AUTO_STRIPES_X_BYTES};
+    const bool stripesOk = fmtOk && d->N * 8 <= AUTO_STRIPES_X_BYTES;
+    const bool eligible[AUTO_N] = {true, fmtOk, stripesOk, stripesOk && serial != 0};
     if (!fmtOk) { d->autoPick[serial] = 0; return EXIT_SUCCESS; }
+    // which formats exist already (the caller's, or the other selection's winner): those are never freed here
     useTiles(d, serial != 0);
-    useStripes(d, serial != 0);
-    const bool hadTiles = d->tiles != nullptr, hadStripes = d->stripes != nullptr;
+    const bool hadTiles = d->tiles != nullptr;
+    useStripes(d, false);
+    const bool hadShared = d->stripes != nullptr;    // shared-stream layout: arrival order and ordered tickets
+    useStripes(d, true);
+    const bool hadOwner = d->stripes != nullptr;     // per-wavefront sub-streams
     hipEvent_t e0 = nullptr, e1 = nullptr;
     HIP_TRY(hipEventCreate(&e0));
     if (hipEventCreate(&e1) != hipSuccess) { (void)hipEventDestroy(e0); ERR("hipSpMVAutoCSR: event creation failed"); return EXIT_FAILURE; }
@@ -784,12 +793,12 @@ int autoSelect(spmat* dMat, DevMat* d, int serial, double* dX, CONFIG cfg, doubl
     float bestMs = 0;
     // Lower bound of a format kernel's time: its bytes per entry at the rate this HBM streams (MI355X_MICROARCH.md: 6.3 TB/s).
     // A candidate whose BOUND is no better than what has already been measured cannot win: its format (12 B/nnz of memory,
-    // 12 B/nnz of temporaries) is not built.  Order: no format, 12 B/nnz, 28 B/nnz.
-    const double boundMs[AUTO_N] = {0.0, (double)d->NZ * 28.0 / 6.3e12 * 1e3, (double)d->NZ * 12.0 / 6.3e12 * 1e3};
-    const int order[AUTO_N] = {0, 2, 1};
+    // 12 B/nnz of temporaries) is not built.  Order: no format, 12 B/nnz (stripes), 28 B/nnz (two-phase).
+    const double boundMs[AUTO_N] = {0.0, (double)d->NZ * 28.0 / 6.3e12 * 1e3, (double)d->NZ * 12.0 / 6.3e12 * 1e3, (double)d->NZ * 12.0 / 6.3e12 * 1e3};
+    const int order[AUTO_N] = {0, 2, 3, 1};
     for (int k = 0; k < AUTO_N; ++k) {
         const int c = order[k];
-        if (!eligible[c]) continue;
+        if (!eligible[c] || !AUTO_CAND[serial][c].fn) continue;
         if (best >= 0 && boundMs[c] >= bestMs / AUTO_REPS) { d->autoMs[serial][c] = 0; continue; }
         // enqueue-only throughout (the library's own timing events belong to the device of spmvHipInit; this may run on another
         // device's stream, spmvHipEnqueueAuto) and no host round trip inside e0..e1
@@ -812,11 +821,15 @@ int autoSelect(spmat* dMat, DevMat* d, int serial, double* dX, CONFIG cfg, doubl
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
     if (best < 0) { ERR("hipSpMVAutoCSR: no candidate kernel ran"); return EXIT_FAILURE; }
-    // the losers' private copies of the matrix (12 B/nnz each) go; formats the caller built before stay
+    // the losers' private copies of the matrix (12 B/nnz each) go; formats that existed before stay.  The shared-stream
+    // stripes layout serves candidate 2 of the reduction-order selection and candidate 3 of the serial-order one.
     useTiles(d, serial != 0);
-    useStripes(d, serial != 0);
     if (best != 1 && d->tiles && !hadTiles) { freeTiles(d->tiles); d->tiles = nullptr; }
-    if (best != 2 && d->stripes && !hadStripes) { freeStripes(d->stripes); d->stripes = nullptr; }
+    const bool keepShared = serial ? best == 3 : best == 2, keepOwner = serial && best == 2;
+    useStripes(d, false);
+    if (!keepShared && d->stripes && !hadShared) { freeStripes(d->stripes); d->stripes = nullptr; }
+    useStripes(d, true);
+    if (!keepOwner && d->stripes && !hadOwner) { freeStripes(d->stripes); d->stripes = nullptr; }
     d->autoPick[serial] = best;
     return EXIT_SUCCESS;
 }

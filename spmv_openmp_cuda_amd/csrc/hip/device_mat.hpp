@@ -54,12 +54,13 @@ struct DevMat {
     // be built).  `*Pref` is the form the explicit launchers and queries use: set by spmvHipBuildTilesOpt / ...StripesOpt.
     TileFormat* tiles = nullptr, *tilesAlt = nullptr;         // built lazily by hipSpMVTilesCSR / spmvHipBuildTiles / the selections
     StripeFormat* stripes = nullptr, *stripesAlt = nullptr;   // built lazily by hipSpMVStripesCSR / spmvHipBuildStripes / the selections
-    bool      tilesPref = false, stripesPref = false;
+    bool      tilesPref = false;
+    int       stripesPref = 0;      // 0 arrival order, 1 owner wavefronts, 2 ordered tickets (spmvStripesOpts.deterministic)
     SellFormat* sell = nullptr;     // built lazily by hipSpMVRowsSELL / spmvHipBuildSell
     // the selections: [0] among the reduction-order kernels (hipSpMVAutoCSR, hipSpMVWarpPerRowCSR), [1] among the
     // serial-order kernels (hipSpMVRowsCSR): index of the launcher chosen for this matrix (-1: not chosen yet) ...
     int       autoPick[2] = {-1, -1};
-    float     autoMs[2][3] = {{0, 0, 0}, {0, 0, 0}};          // ... and what each candidate took (0 = not tried)
+    float     autoMs[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};    // ... and what each candidate took (0 = not tried)
 };
 
 int  buildSell(DevMat* d);                                      // sell.hip
@@ -69,8 +70,8 @@ size_t sellBytes(const DevMat* d);
 
 int  buildStripes(DevMat* d, const spmvStripesOpts* opts = nullptr);   // stripes.hip; explicit options replace an existing format
 void freeStripes(StripeFormat* f);
-void useStripes(DevMat* d, bool deterministic);                 // make that form the active one (d->stripes may then be null)
-int  enqueueStripes(DevMat* d, const double* x, double* y, hipStream_t stream, dim3* grid = nullptr, dim3* block = nullptr);
+void useStripes(DevMat* d, bool subStreams);                    // make that LAYOUT the active one (d->stripes may then be null)
+int  enqueueStripes(DevMat* d, const double* x, double* y, hipStream_t stream, int mode, dim3* grid = nullptr, dim3* block = nullptr);
 size_t stripesBytes(const DevMat* d);
 void stripesInfo(const DevMat* d, spmvStripesInfo* out);
 

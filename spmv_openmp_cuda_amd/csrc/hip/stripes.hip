@@ -37,12 +37,20 @@
 //
 // The format is built ON THE DEVICE from the device CSR (rocPRIM radix sort of (bin, column) keys; c3: ~60 ms).
 //
-// DETERMINISTIC form (spmvStripesOpts.deterministic): every row of a bin is OWNED by one of the workgroup's
-// wavefronts (local row mod 4); each wavefront has its own column-ordered sub-stream of the bin and walks it in
-// program order, so a row's products are added by one wavefront in ascending column order -- the order of the
-// serial oracle -- whatever the scheduler does.  No ticket counter, no staggered start.  The four wavefronts
-// still sweep x together (each sub-stream spans all columns), but a gather instruction now covers 64 neighbours
-// of a QUARTER of the bin's entries, so it touches more lines (c3: ~60 instead of ~47 per 64 entries).
+// DETERMINISTIC forms (spmvStripesOpts.deterministic): a row's products are added in ascending column order -- the
+// order of the serial oracle -- whatever the scheduler does; y is bit-identical to sgemvSerial.  Two ways to get there,
+// neither always the faster, so the serial-order selection of hipSpMVRowsCSR measures both:
+//   1 "owner wavefronts": every row of a bin is OWNED by one of the workgroup's wavefronts (local row mod 4); each
+//     wavefront has its own column-ordered sub-stream of the bin and walks it in program order.  No ticket counter, no
+//     hand-over.  The four wavefronts still sweep x together (each sub-stream spans all columns), but a gather instruction
+//     covers 64 neighbours of a QUARTER of the bin's entries, so it touches more lines (c3: ~60 instead of ~47 per 64
+//     entries: 1.69 ms against 0.87); on matrices with column locality it costs almost nothing (+-16 Ki band 0.44 against
+//     0.42 ms, 3-D stencil 0.188 against 0.185).  Its format is a layout of its own (sub-stream-major).
+//   2 "ordered tickets": the SAME format and the same shared stream as the arrival-order kernel (tickets, full-density
+//     gathers), but the batches ADD in ticket order: a wavefront spins on an LDS word until the batch before its own has
+//     been added and hands over after its adds (LDS operations of a wavefront execute in issue order).  Streams and
+//     gathers stay in flight while it waits.  c3 1.05 ms, c2 0.135 against 0.154 -- but where lanes of one instruction
+//     meet in a row (banded matrices: long add phases) the serial chain shows: +-16 Ki band 0.64 ms.
 #include <hip/hip_runtime.h>
 #include <cstring>
 #include <rocprim/device/device_radix_sort.hpp>
@@ -69,7 +77,7 @@ struct StripeFormat {
     uint32_t  B = 0, R = 0;                         // bins, rows of the highest bin
     uint32_t  subs = 1;                             // column-ordered sub-streams per bin: 1, or SB_WAVES in the deterministic form
     uint64_t  nnz = 0, nSteps = 0;
-    bool      wide = false, det = false, det2 = false;
+    bool      wide = false, det = false;            // det: the sub-stream-major layout of the owner-wavefront form
     double*   val = nullptr;                        // [nSteps * 128] sub-stream-major, column order inside a sub-stream, each padded to whole steps
     uint32_t* cr = nullptr;                         // narrow: (column - stepBase) << 15 | local row;  wide: column
     uint16_t* lrowW = nullptr;                      // wide only: local row
@@ -427,12 +435,14 @@ void stripesInfo(const DevMat* d, spmvStripesInfo* out) {
     if (!f) return;
     out->nBins = f->B; out->rowsPerBin = f->R; out->grid = f->grid; out->spread = f->spread;
     out->wide = f->wide ? 1 : 0; out->deterministic = f->det ? 1 : 0; out->buildMs = f->buildMs; out->bytes = f->bytes;
+    // (deterministic = 1: the owner-wavefront layout; the caller overrides it with 2 when it runs this layout in ticket order)
 }
 
-// `opts` == nullptr: automatic arrival-order format, kept if one exists.  Explicit options: the existing format of that FORM
-// is replaced (the other form, if the handle holds it, is untouched).
+// `opts` == nullptr: automatic format of the shared-stream layout, kept if one exists.  Explicit options: the existing format of
+// that LAYOUT is replaced (the other layout, if the handle holds it, is untouched).  Layouts: opts->deterministic == 1 -> per-
+// wavefront sub-streams; 0 and 2 -> one stream per bin (run in arrival order or in ticket order: a choice of the launch).
 int buildStripes(DevMat* d, const spmvStripesOpts* opts) {
-    useStripes(d, opts && opts->deterministic);
+    useStripes(d, opts && opts->deterministic == 1);
     if (d->stripes && !opts) return EXIT_SUCCESS;
     if (d->kind != Kind::CSR) return EXIT_FAILURE;
     const spmvStripesOpts o = opts ? *opts : spmvStripesOpts{0, 0, -1, -1, 0};
@@ -445,8 +455,8 @@ int buildStripes(DevMat* d, const spmvStripesOpts* opts) {
     SB_TRY(hipGetDevice(&dev));
     SB_TRY(hipDeviceGetAttribute(&cusDev, hipDeviceAttributeMultiprocessorCount, dev));
     cusDev = std::max(1, cusDev);
-    if (o.rowsPerBin > SB_R_MAX || o.grid > (unsigned)cusDev || o.spread < -1 || o.spread > 1024) {
-        fprintf(stderr, "libspmvhip: stripes: options out of range (rowsPerBin 0..%u, grid 0..%d, spread -1..1024)\n", SB_R_MAX, cusDev);
+    if (o.rowsPerBin > SB_R_MAX || o.grid > (unsigned)cusDev || o.spread < -1 || o.spread > 1024 || o.deterministic < 0 || o.deterministic > 2) {
+        fprintf(stderr, "libspmvhip: stripes: options out of range (rowsPerBin 0..%u, grid 0..%d, spread -1..1024, deterministic 0..2)\n", SB_R_MAX, cusDev);
         return EXIT_FAILURE;
     }
     if (d->stripes) { freeStripes(d->stripes); d->stripes = nullptr; }
@@ -475,12 +485,11 @@ int buildStripes(DevMat* d, const spmvStripesOpts* opts) {
 
     StripeFormat* f = new StripeFormat;
     f->opts = o;
-    f->det = o.deterministic != 0;
-    f->det2 = o.deterministic == 2;
-    f->subs = f->det && !f->det2 ? SB_WAVES : 1;
+    f->det = o.deterministic == 1;
+    f->subs = f->det ? SB_WAVES : 1;
     f->B = B; f->R = R; f->nnz = nnz;
     f->grid = std::min<uint32_t>(B, cus);
-    f->spread = f->det ? 0u : o.spread >= 0 ? (uint32_t)o.spread : SB_SPREAD;
+    f->spread = o.spread >= 0 ? (uint32_t)o.spread : SB_SPREAD;          // (used by the arrival-order launch only)
     const uint64_t nGroups = (uint64_t)B * f->subs;
     auto fail = [&](const char* what) { fprintf(stderr, "libspmvhip: stripes: %s failed\n", what); freeStripes(f); return EXIT_FAILURE; };
     TempBuf keys, keysOut, idx, perm, rowOf, sortTmp, dStart, dOverflow;
@@ -564,12 +573,12 @@ int buildStripes(DevMat* d, const spmvStripesOpts* opts) {
 // the same microsecond and every one of them waits for the fabric; a few microseconds apart the first to arrive pays and
 // the rest hit: the first quarter of a bin 113 instead of 123 us and the bin 404 instead of 417 us on c3.  Past ~2 % the
 // tail of the pack outlives its lines in the 4 MiB L2 (c3: 6.4 % 1.05 ms, 100 % 2.96 ms; profiles/r02_stripes_spread.log).
-int enqueueStripes(DevMat* d, const double* x, double* y, hipStream_t stream, dim3* grid, dim3* block) {
+// mode 0: arrival order; 1: owner wavefronts (needs the sub-stream layout); 2: ordered tickets (needs the shared-stream layout)
+int enqueueStripes(DevMat* d, const double* x, double* y, hipStream_t stream, int mode, dim3* grid, dim3* block) {
     const StripeFormat* f = d->stripes;
-    if (!f) return EXIT_FAILURE;
+    if (!f || mode < 0 || mode > 2 || (mode == 1) != f->det) return EXIT_FAILURE;
     if (grid) *grid = dim3(f->grid);
     if (block) *block = dim3(SB_THREADS);
-    const int mode = f->det2 ? 2 : f->det ? 1 : 0;
     if (f->wide) { if (mode == 2) launchSpmv<true, 2>(f, x, y, stream); else if (mode == 1) launchSpmv<true, 1>(f, x, y, stream); else launchSpmv<true, 0>(f, x, y, stream); }
     else         { if (mode == 2) launchSpmv<false, 2>(f, x, y, stream); else if (mode == 1) launchSpmv<false, 1>(f, x, y, stream); else launchSpmv<false, 0>(f, x, y, stream); }
     return hipGetLastError() == hipSuccess ? EXIT_SUCCESS : EXIT_FAILURE;

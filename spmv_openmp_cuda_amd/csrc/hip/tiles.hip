@@ -55,10 +55,7 @@ constexpr uint32_t PB_R_MAX   = 20000;             // rows per bin: <= 156 KiB o
 constexpr uint32_t PB_CUS_DEFAULT = 256;           // compute units when the device does not say (phase 2 keeps one workgroup per CU)
 constexpr uint32_t PB_CHUNK   = 1u << 17;           // entries of one slice handled by one phase-1 workgroup
 constexpr int      PB_THREADS = 1024;
-#ifndef SPMV_PD_WAVES
-#define SPMV_PD_WAVES 8
-#endif
-constexpr uint32_t PD_WAVES   = SPMV_PD_WAVES;     // deterministic form: wavefronts of a phase-2 workgroup = sub-bins of a bin
+constexpr uint32_t PD_WAVES   = 4;                 // deterministic form: wavefronts of a phase-2 workgroup = sub-bins of a bin (c5: 4 -> 9.4 ms, 8 -> 10.1, 16 -> 11.2)
 constexpr int      PD_THREADS = PD_WAVES * 64;
 constexpr size_t   PB_RESIDENT_BYTES = 288ull << 20; // products up to this size stay in the 256 MiB Infinity Cache between the phases (c2, 244 MiB: 0.156 ms plain vs 0.176 ms nt stores)
 
@@ -499,9 +496,9 @@ __global__ __launch_bounds__(PB_THREADS) void pb_reduce_kernel(
 // receives its products from ONE wavefront in ascending column order (lanes of one instruction that meet in a row are served
 // in lane order), which is the order of the serial oracle, whatever the scheduler does and however the rows were cut into
 // bins or shards.
-// With a sub-bin per wavefront the tiles are PD_WAVES times shorter than a bin's (c5: 10 entries), and the scalar walk
+// With a sub-bin per wavefront the tiles are PD_WAVES times shorter than a bin's (c5: 20 entries), and the scalar walk
 // through the tile table that serves the arrival-order kernel -- one dependent s_load per tile boundary -- becomes the
-// bottleneck (first version, 4 wavefronts: phase 2 of c5 8.7 ms against 3.0).  This form therefore stores, per bin-major
+// bottleneck (first version: phase 2 of c5 8.7 ms against 3.0).  This form therefore stores, per bin-major
 // position, the slice-major position of its product (`pidx`, +4 B/nnz) and runs as a three-stage software pipeline like
 // the stripes kernel: stream (pidx, local row; non-temporal) two batches ahead, product gather one batch ahead (default
 // policy: neighbouring sub-bins read the same lines), LDS adds -- vmcnt counts in issue order, so a gather is only

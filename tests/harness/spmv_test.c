@@ -159,9 +159,9 @@ int main(int argc, char** argv) {
             if (testSpMVImplHip(SpmvCUDA_CSRFuncs[f], &dMat, mat->M, dVect, dOutV, outV, oracleOut, &avg)) goto _free;
             printf("#tight CSR %u\tmax|dy|/sum|a x|:%le\n", f, oracleScaledError(matCSR, vector, oracleOut, outV));
             if (f == 0 || f == SpmvCUDA_CSRFuncs_WarpPerRowIdx || f == SpmvCUDA_CSRFuncs_AutoIdx) {   /* which kernel the name resolved to */
-                double ms3[3] = {0, 0, 0};
+                double ms3[4] = {0, 0, 0, 0};
                 const char* pick = f == 0 ? spmvHipAutoChoiceRows(&dMat, ms3) : spmvHipAutoChoice(&dMat, ms3);
-                printf("#auto CSR %u\tpick:%s\tmsStream:%le msTiles:%le msStripes:%le\n", f, pick ? pick : "(none)", ms3[0], ms3[1], ms3[2]);
+                printf("#auto CSR %u\tpick:%s\tmsStream:%le msTiles:%le msStripes:%le msStripesOrdered:%le\n", f, pick ? pick : "(none)", ms3[0], ms3[1], ms3[2], ms3[3]);
             }
             char tagc[32];
             snprintf(tagc, sizeof tagc, "HIP CSR %u", f);

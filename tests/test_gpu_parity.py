@@ -271,10 +271,11 @@ def test_full_size_spot_checks(api, oracle, key):
             tb, sb = api.lib.spmvHipTilesBytes(C.byref(dm.handle)), api.lib.spmvHipStripesBytes(C.byref(dm.handle))
             assert (tb > 0) == (expect == b"hipSpMVTilesCSR") and (sb > 0) == (expect == b"hipSpMVStripesCSR")
         if (launcher, variant) == ("hipSpMVRowsCSR", 2):    # the serial-order selection: measured, a format kernel wins at this size
-            ms = (C.c_double * 3)()
+            ms = (C.c_double * 4)()
             pick = api.lib.spmvHipAutoChoiceRows(C.byref(dm.handle), ms)
-            assert pick in (b"hipSpMVTilesCSR(deterministic)", b"hipSpMVStripesCSR(deterministic)"), pick
-            assert ms[0] > 0 and min(t for t in ms if t > 0) == ms[(b"hipSpMVRowsCSR", b"hipSpMVTilesCSR(deterministic)", b"hipSpMVStripesCSR(deterministic)").index(pick)]
+            names = (b"hipSpMVRowsCSR", b"hipSpMVTilesCSR(deterministic)", b"hipSpMVStripesCSR(owner wavefronts)", b"hipSpMVStripesCSR(ordered tickets)")
+            assert pick in names[1:], pick
+            assert ms[0] > 0 and min(t for t in ms if t > 0) == ms[names.index(pick)]
         # linearity (size-independent property): A(2x) == 2 A(x) exactly in binary fp
         dx2 = api.DeviceVector(w.N).up(2.0 * x)
         dy.poison()
@@ -611,14 +612,14 @@ def test_auto_launcher_picks_and_remembers(api, oracle):
     x2 = _x(rng, N2)
     y2_ref = oracle.csr_serial(IRP2, JA2, AS2, x2)
     d2 = api.spMatCpyCSR(api.HostCSR(M2, N2, IRP2, JA2, AS2))
-    ms = (C.c_double * 3)()
+    ms = (C.c_double * 4)()
     for call in range(3):
         y2 = _run(api, "hipSpMVAutoCSR", d2, x2, M2)
         assert not np.isnan(y2).any() and tight_error(IRP2, JA2, AS2, x2, y2_ref, y2) <= TIGHT, call
         name = api.lib.spmvHipAutoChoice(C.byref(d2.handle), ms)
         assert name in (b"hipSpMVWarpPerRowCSR", b"hipSpMVTilesCSR", b"hipSpMVStripesCSR")
-        assert all(t > 0 for t in ms), list(ms)                  # all three were eligible and measured
-        assert ms[(b"hipSpMVWarpPerRowCSR", b"hipSpMVTilesCSR", b"hipSpMVStripesCSR").index(name)] == min(ms)
+        assert all(t > 0 for t in ms[:3]) and ms[3] == 0, list(ms)    # all three were eligible and measured
+        assert ms[(b"hipSpMVWarpPerRowCSR", b"hipSpMVTilesCSR", b"hipSpMVStripesCSR").index(name)] == min(ms[:3])
     # only the winner keeps a private copy of the matrix
     tb, sb = api.lib.spmvHipTilesBytes(C.byref(d2.handle)), api.lib.spmvHipStripesBytes(C.byref(d2.handle))
     assert (tb > 0) == (name == b"hipSpMVTilesCSR") and (sb > 0) == (name == b"hipSpMVStripesCSR")
@@ -629,7 +630,8 @@ def test_auto_launcher_picks_and_remembers(api, oracle):
         yr = _run(api, "hipSpMVRowsCSR", d2, x2, M2)
         assert np.array_equal(yr, y2_ref), call
         rname = api.lib.spmvHipAutoChoiceRows(C.byref(d2.handle), ms)
-        assert rname in (b"hipSpMVRowsCSR", b"hipSpMVTilesCSR(deterministic)", b"hipSpMVStripesCSR(deterministic)") and all(t > 0 for t in ms)
+        assert rname in (b"hipSpMVRowsCSR", b"hipSpMVTilesCSR(deterministic)", b"hipSpMVStripesCSR(owner wavefronts)",
+                         b"hipSpMVStripesCSR(ordered tickets)") and all(t > 0 for t in ms)
     assert api.lib.spmvHipAutoChoice(C.byref(d2.handle), None) == name              # untouched
     y2 = _run(api, "hipSpMVAutoCSR", d2, x2, M2)                                    # and still runs its own format
     assert tight_error(IRP2, JA2, AS2, x2, y2_ref, y2) <= TIGHT
@@ -779,7 +781,8 @@ def test_stripes_rotated_sweeps(api, oracle, spread, grid, rows, wide):
 
 @pytest.mark.parametrize("name", list(CASES))
 def test_stripes_deterministic_form_is_the_serial_order(api, oracle, name):
-    """spmvStripesOpts.deterministic: every row is added by ONE wavefront in ascending column order, so y is (a) the same
+    """spmvStripesOpts.deterministic (1: every row is added by ONE wavefront in ascending column order; 2: one shared stream
+    whose batches add in ticket order): y is (a) the same
     bits in every run, (b) the same bits whatever the bin layout (bins of 64, 700 or 20 000 rows; 1, 3 or all
     workgroups), (c) the same bits when the rows are computed as three separate row blocks (the shape of a 3-rank run)
     and (d) the bits of the serial oracle -- the columns of every row ascend in these matrices, as the reference's loader
@@ -791,11 +794,12 @@ def test_stripes_deterministic_form_is_the_serial_order(api, oracle, name):
     y_ref = oracle.csr_serial(IRP, JA, AS, x)
     dmat = api.spMatCpyCSR(api.HostCSR(M, N, IRP, JA, AS))
     ys = []
-    for rows, grid in ((0, 0), (64, 3), (700, 1), (0, 0)):
-        api.build_stripes(dmat, rowsPerBin=rows, grid=grid, deterministic=True)
-        assert api.stripes_info(dmat).deterministic == 1
-        for _ in range(3):
-            ys.append(_run(api, "hipSpMVStripesCSR", dmat, x, M))
+    for form in (1, 2):                                      # owner wavefronts / ordered tickets
+        for rows, grid in ((0, 0), (64, 3), (700, 1), (0, 0)):
+            api.build_stripes(dmat, rowsPerBin=rows, grid=grid, deterministic=form)
+            assert api.stripes_info(dmat).deterministic == form
+            for _ in range(3):
+                ys.append(_run(api, "hipSpMVStripesCSR", dmat, x, M))
     dmat.free()
     for y in ys:
         assert np.array_equal(y, ys[0])
@@ -811,7 +815,7 @@ def test_stripes_deterministic_form_is_the_serial_order(api, oracle, name):
             parts.append(np.zeros(r1 - r0))
             continue
         blk = api.spMatCpyCSR(api.HostCSR(r1 - r0, N, IRP[r0:r1 + 1] - IRP[r0], JA[b0:b1], AS[b0:b1]))
-        api.build_stripes(blk, deterministic=True)
+        api.build_stripes(blk, deterministic=1 + len(parts) % 2)
         parts.append(_run(api, "hipSpMVStripesCSR", blk, x, r1 - r0))
         blk.free()
     assert np.array_equal(np.concatenate(parts), ys[0])
@@ -887,8 +891,9 @@ def test_deterministic_forms_at_full_size(api, oracle, key):
         ja, as_ = oracle.synth_fill(w.N, r0, irp[r0:r1 + 1], synth.SEED_STRUCT + w.cfg, synth.SEED_VAL + w.cfg, w.band)
         refs.append(oracle.csr_serial_dev((irp[r0:r1 + 1] - irp[r0]).astype(np.uint32), ja, as_, x))
     results = {}
-    for launcher, build in (("hipSpMVTilesCSR", api.build_tiles),) + ((("hipSpMVStripesCSR", api.build_stripes),) if key == "c3" else ()):
-        build(dm, deterministic=True)
+    for launcher, build, form in (("hipSpMVTilesCSR", api.build_tiles, 1),) + ((("hipSpMVStripesCSR", api.build_stripes, 1),
+                                                                                 ("hipSpMVStripesCSR", api.build_stripes, 2)) if key == "c3" else ()):
+        build(dm, deterministic=form)
         first = None
         for _ in range(5):
             dy.poison()
@@ -901,6 +906,8 @@ def test_deterministic_forms_at_full_size(api, oracle, key):
                     assert np.array_equal(y[r0:r1], yr), (launcher, r0)
             else:
                 assert np.array_equal(y, first), launcher
+        if launcher in results:
+            assert np.array_equal(results[launcher], first)
         results[launcher] = first
     if len(results) == 2:
         assert np.array_equal(results["hipSpMVTilesCSR"], results["hipSpMVStripesCSR"])
