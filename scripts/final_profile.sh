@@ -27,9 +27,9 @@ prof c2_stripes tfw --workload c2 --launcher hipSpMVStripesCSR
 prof c2_sell tfw --workload c2 --launcher hipSpMVRowsSELL
 prof c3b tfw --workload c3b
 # the serial-order default of hipSpMVRowsCSR (deterministic two-phase / stripes forms)
-prof c5_serial tf --workload c5 --launcher hipSpMVRowsCSR --variant 2
-prof c3_serial tf --workload c3 --launcher hipSpMVRowsCSR --variant 2
-prof c2_serial tf --workload c2 --launcher hipSpMVRowsCSR --variant 2
+prof c5_serial tfw --workload c5 --launcher hipSpMVRowsCSR --variant 2
+prof c3_serial tfw --workload c3 --launcher hipSpMVRowsCSR --variant 2
+prof c2_serial tfw --workload c2 --launcher hipSpMVRowsCSR --variant 2
 # the reference's kind of matrix: every CSR and ELL kernel on the 3-D stencil stand-in (and the road network)
 pstruct() {
   tag=$1; shift

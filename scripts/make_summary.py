@@ -7,6 +7,10 @@ import collections, csv, glob, json, os, shutil, sys
 RND = sys.argv[1] if len(sys.argv) > 1 else "r03"
 O = f"gpurun_out/{RND}c"
 def short(n): return n.replace("void ", "").replace("spmvhip::", "").replace("(anonymous namespace)::", "").split("(")[0]
+def latest(pattern):
+    """gpurun MERGES a call's files into gpurun_out/: of several runs of the same pass keep the newest file only"""
+    files = sorted(glob.glob(pattern), key=os.path.getmtime)
+    return files[-1:]
 sha = open(f"{O}/libspmvhip.sha256").read().strip()
 lines = [f"# {RND} profile summary (rocprofv3, one MI355X) -- `scripts/final_profile.sh {RND}` + `scripts/make_summary.py {RND}`", "",
          f"Library profiled: `libspmvhip.so` sha256 `{sha}`.", "",
@@ -27,17 +31,21 @@ LAUNCHER = (("pb_reduce_det", "hipSpMVRowsCSR"), ("sb_spmv_kernel<false, true", 
             ("csr_stream", "hipSpMVWarpPerRowCSR"))
 for tag in wlname:
     tr = collections.defaultdict(list)
-    for p in glob.glob(f"{O}/{tag}/trace/*/*_kernel_trace.csv"):
+    for p in latest(f"{O}/{tag}/trace/*/*_kernel_trace.csv"):
         for r in csv.DictReader(open(p)):
             k = short(r["Kernel_Name"])
             if any(x in k for x in KEEP): tr[k].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
     if not tr: continue
     pm = collections.defaultdict(lambda: collections.defaultdict(list))
-    for p in glob.glob(f"{O}/{tag}/pmc_*/*/*_counter_collection.csv"):
+    for p in [f for d in glob.glob(f"{O}/{tag}/pmc_*") for f in latest(f"{d}/*/*_counter_collection.csv")]:
         for r in csv.DictReader(open(p)):
             k = short(r["Kernel_Name"])
             if k in tr: pm[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
-    maxcalls = max(len(v) for v in tr.values())      # auto mode runs every candidate a few times during warm-up
+    # the block's timed launcher = the kernel with the most calls (the candidates of the bench's own pick and of the library's
+    # two selections run a few times each, too); the two-phase launcher is two kernels
+    top = max(tr, key=lambda k: len(tr[k]))
+    maxcalls = len(tr[top])
+    tr = {k: v for k, v in tr.items() if k == top or (top.startswith("pb_") and k.startswith("pb_"))}
     lines += [f"## {tag}: {wlname[tag]}  (algorithmic {alg[tag] / 1e9:.2f} GB)", "",
               "| kernel | calls | avg us | min us | HBM read GB | HBM written GB | L2 hit | WAIT_ANY / WAIT_INST_ANY / ACTIVE of wave cycles |",
               "|---|---|---|---|---|---|---|---|"]
@@ -64,13 +72,13 @@ STRUCT = {"stencil": ("stencil3d-500x100x100 (5 M rows, 88.9 M entries, 18 slots
 SKEEP = KEEP + ("ell_",)
 for tag, (title, bcsr) in STRUCT.items():
     tr = collections.defaultdict(list)
-    for p in glob.glob(f"{O}/{tag}/trace/*/*_kernel_trace.csv"):
+    for p in latest(f"{O}/{tag}/trace/*/*_kernel_trace.csv"):
         for r in csv.DictReader(open(p)):
             k = r["Kernel_Name"].replace("void ", "").replace("spmvhip::", "").replace("(anonymous namespace)::", "").split("(")[0]
             if any(x in k for x in SKEEP): tr[k].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
     if not tr: continue
     pm = collections.defaultdict(lambda: collections.defaultdict(list))
-    for p in glob.glob(f"{O}/{tag}/pmc_*/*/*_counter_collection.csv"):
+    for p in [f for d in glob.glob(f"{O}/{tag}/pmc_*") for f in latest(f"{d}/*/*_counter_collection.csv")]:
         for r in csv.DictReader(open(p)):
             k = r["Kernel_Name"].replace("void ", "").replace("spmvhip::", "").replace("(anonymous namespace)::", "").split("(")[0]
             if k in tr: pm[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
@@ -87,7 +95,7 @@ for tag, (title, bcsr) in STRUCT.items():
 os.makedirs("profiles", exist_ok=True)
 open(f"profiles/{RND}_summary.md", "w").write("\n".join(lines) + "\n")
 json.dump(traffic, open("profiles/traffic.json", "w"), indent=1)
-for p in glob.glob(f"{O}/default/trace/*/*_kernel_stats.csv") or glob.glob(f"{O}/c5/trace/*/*_kernel_stats.csv"):
+for p in latest(f"{O}/default/trace/*/*_kernel_stats.csv") or latest(f"{O}/c5/trace/*/*_kernel_stats.csv"):
     shutil.copy(p, f"profiles/{RND}_default_bench_kernel_stats.csv")
 if os.path.exists(f"{O}/default.trace.json"):          # the line the default command printed under the profiler, for the cross-check
     shutil.copy(f"{O}/default.trace.json", f"profiles/{RND}_default_bench_under_trace.json")
