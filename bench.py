@@ -55,6 +55,9 @@ def parse():
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-extra", action="store_true", help="skip the secondary workloads measured at N=1")
     p.add_argument("--cpu-sample-nnz", type=int, default=100_000_000)
+    p.add_argument("--y-hash", action="store_true",
+                   help="add `y_sha256`, the hash of the bytes of the timed kernel's full y (rank 0's copy), to the line: two runs with a "
+                        "serial-order launcher (--launcher hipSpMVRowsCSR) must agree on it whatever the number of ranks")
     p.add_argument("--only-structured", default="",
                    help="measure only the structured stand-in whose name contains this string (stencil3d, road, blocks; 'all' = the "
                         "three) and print that block alone -- for profiling the ELL / CSR kernels on the reference's kind of matrix")
@@ -589,6 +592,7 @@ def full_rows_parity(y_cpu, y_gpu_head):
 
 
 _ROWS_VARIANT = [1]
+_Y_HASH = [False]
 
 
 def set_rows_variant(api, v):
@@ -604,6 +608,8 @@ def measure_block(api, synth, torch, w, launcher, steps, warmup, candidates=None
     y_t = ctx["y"]
     win = OracleWindows(synth, w, ctx["irp"], ctx["x_host"], ctx["lens"])
     parity = win.check(lambda a, b: y_t[a:b].cpu().numpy())
+    if _Y_HASH[0]:
+        res["y_sha256"] = hashlib.sha256(y_t.cpu().numpy().tobytes()).hexdigest()
     if cpu_rows:
         import numpy as np
         rows = w.N if cpu_rows >= int(ctx["irp"][-1]) else int(np.searchsorted(ctx["irp"], cpu_rows, side="right") - 1)
@@ -986,6 +992,8 @@ def run_single(args, api, synth, torch, w):
                      "extra_device_bytes": res.get("extra_device_bytes")},
         "parity": res["parity"],
     }
+    if "y_sha256" in res:
+        line["y_sha256"] = res["y_sha256"]
     if "cpu_baseline" in res:
         line["cpu_baseline"] = res["cpu_baseline"]
     if "c3" in extra:
@@ -1281,6 +1289,8 @@ def run_multi(args, api, synth, torch, dist, w, world, rank, local):
                                              "bit_identical_to_serial_oracle_on_every_rank": bool(float(ok_s[0]) == 1.0),
                                              "rank0": serial_par}},
         }
+        if args.y_hash:
+            line["y_sha256"] = hashlib.sha256(y.cpu().numpy().tobytes()).hexdigest()
         emit(line)
         if not parity_ok:
             raise SystemExit(f"PARITY FAILURE at N = {world}: {line['parity']}")
@@ -1385,6 +1395,7 @@ def main():
     w = synth.WORKLOADS[args.workload]
     if args.scale != 1.0:
         w = synth.scaled(w, args.scale)
+    _Y_HASH[0] = bool(args.y_hash)
     if multi:
         run_multi(args, api, synth, torch, dist, w, world, rank, local)
         api.spmvHipFinalize()

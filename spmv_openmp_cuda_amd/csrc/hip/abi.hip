@@ -199,6 +199,19 @@ __global__ __launch_bounds__(256) void csr_to_ell_kernel(uint32_t M, uint32_t K,
     }
 }
 
+// one wavefront per row: does any row hold a column smaller than its predecessor?  (the deterministic format kernels add a
+// row's products in ascending COLUMN order, which is the serial oracle's ascending-j order only for such rows)
+template <typename I>
+__global__ __launch_bounds__(256) void csr_unsorted_kernel(uint64_t M, const I* __restrict__ IRP, const uint32_t* __restrict__ JA,
+                                                           uint32_t* __restrict__ flag) {
+    const uint64_t r = linear_block() * 4 + threadIdx.x / 64;
+    if (r >= M) return;
+    const uint64_t b = IRP[r], e = IRP[r + 1];
+    bool bad = false;
+    for (uint64_t j = b + threadIdx.x % 64; j + 1 < e; j += 64) bad |= JA[j] > JA[j + 1];
+    if (bad) atomicOr(flag, 1u);
+}
+
 template <bool SEQ>
 static void launchStream2(DevMat* d, double* x, double* y) {
     if (d->irpBytes == 4)
@@ -776,8 +789,24 @@ const AutoCand AUTO_CAND[2][AUTO_N] = {
 int autoSelect(spmat* dMat, DevMat* d, int serial, double* dX, CONFIG cfg, double* dY) {
     const bool fmtOk = d->NZ >= AUTO_MIN_NNZ && d->NZ < IRP32_LIMIT;
     const bool stripesOk = fmtOk && d->N * 8 <= AUTO_STRIPES_X_BYTES;
-    const bool eligible[AUTO_N] = {true, fmtOk, stripesOk, stripesOk && serial != 0};
+    bool eligible[AUTO_N] = {true, fmtOk, stripesOk, stripesOk && serial != 0};
     if (!fmtOk) { d->autoPick[serial] = 0; return EXIT_SUCCESS; }
+    if (serial) {
+        // the serial-order contract is ascending j; the deterministic format kernels deliver ascending COLUMNS: the same thing
+        // only when no row holds a column below its predecessor (the reference's loader guarantees it, parser.c:195-202; a
+        // caller's own device CSR may not) -- otherwise the LDS-stream kernel, which walks j, is the only candidate
+        uint32_t* dFlag = nullptr;
+        uint32_t unsorted = 1;
+        if (hipMalloc(&dFlag, 4) == hipSuccess && hipMemsetAsync(dFlag, 0, 4, S.stream) == hipSuccess) {
+            const dim3 grid = grid2d((d->M + 3) / 4, 256);
+            if (d->irpBytes == 4) hipLaunchKernelGGL((csr_unsorted_kernel<uint32_t>), grid, dim3(256), 0, S.stream, d->M, static_cast<const uint32_t*>(d->IRP), d->JA, dFlag);
+            else                  hipLaunchKernelGGL((csr_unsorted_kernel<uint64_t>), grid, dim3(256), 0, S.stream, d->M, static_cast<const uint64_t*>(d->IRP), d->JA, dFlag);
+            if (hipMemcpyAsync(&unsorted, dFlag, 4, hipMemcpyDeviceToHost, S.stream) != hipSuccess || hipStreamSynchronize(S.stream) != hipSuccess) unsorted = 1;
+        }
+        (void)hipFree(dFlag);
+        (void)hipGetLastError();
+        if (unsorted) { d->autoPick[serial] = 0; return EXIT_SUCCESS; }
+    }
     // which formats exist already (the caller's, or the other selection's winner): those are never freed here
     useTiles(d, serial != 0);
     const bool hadTiles = d->tiles != nullptr;

@@ -647,6 +647,32 @@ def test_auto_launcher_picks_and_remembers(api, oracle):
     de.free()
 
 
+def test_serial_order_contract_on_rows_with_unsorted_columns(api, oracle):
+    """hipSpMVRowsCSR promises ascending-j sums.  Its deterministic format kernels add in ascending COLUMN order, which is
+    the same only when the columns of every row ascend; a caller's CSR with shuffled rows must therefore be served by the
+    kernel that walks j (no format is built), and y must still be the oracle's bits -- while the reduction-order selection
+    is free to use any kernel."""
+    import ctypes as C
+    rng = np.random.default_rng(77)
+    M = N = 50_000
+    IRP, JA, AS = random_csr(rng, M, N, np.full(M, 8))               # 400 k entries: large enough for the selections to measure
+    JA, AS = JA.copy(), AS.copy()
+    for r in range(0, M, 3):                                          # shuffle the entries of every third row
+        b, e = int(IRP[r]), int(IRP[r + 1])
+        p = rng.permutation(e - b)
+        JA[b:e], AS[b:e] = JA[b:e][p], AS[b:e][p]
+    x = _x(rng, N)
+    y_ref = oracle.csr_serial(IRP, JA, AS, x)                         # ascending j, whatever the columns
+    dm = api.spMatCpyCSR(api.HostCSR(M, N, IRP, JA, AS))
+    for _ in range(2):
+        assert np.array_equal(_run(api, "hipSpMVRowsCSR", dm, x, M), y_ref)
+    assert api.lib.spmvHipAutoChoiceRows(C.byref(dm.handle), None) == b"hipSpMVRowsCSR"
+    assert api.lib.spmvHipTilesBytes(C.byref(dm.handle)) == 0 and api.lib.spmvHipStripesBytes(C.byref(dm.handle)) == 0
+    y = _run(api, "hipSpMVWarpPerRowCSR", dm, x, M)
+    assert tight_error(IRP, JA, AS, x, y_ref, y) <= TIGHT
+    dm.free()
+
+
 def test_launchers_capture_into_a_hip_graph(api, oracle):
     """With spmvHipSetSync(0) a launcher only enqueues kernels on the library stream -- no event, no allocation, no
     synchronisation once its format exists -- so a solver's inner loop can be captured into a HIP graph (torch's

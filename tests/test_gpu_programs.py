@@ -169,3 +169,25 @@ def test_bench_spawns_its_own_ranks():
     line = json.loads(lines[0])
     assert line["n_gpus"] == 2 and line["metric"] == "spmv_gflops" and line["value"] > 0
     assert line["parity"]["ok"] is True
+
+
+def test_serial_order_y_is_the_same_bits_on_one_rank_and_on_three():
+    """The whole y of `hipSpMVRowsCSR` in its default (serial-order) variant, hashed: the 1-rank bench and a 3-rank
+    shared-GPU rehearsal (three processes, each computing a third of the rows with whatever serial-order kernel its own
+    selection picked, y assembled through the exchange) must produce byte-identical vectors ("gathered y
+    bitwise equal to the 1-GPU y" -- here for the fast kernels, not only for the LDS-stream one)."""
+    import json
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT",
+                                                              "TORCHELASTIC_RUN_ID", "GROUP_RANK", "LOCAL_WORLD_SIZE")}
+    common = ["--workload", "c3", "--scale", "0.05", "--steps", "2", "--warmup", "1", "--launcher", "hipSpMVRowsCSR", "--variant", "2",
+              "--y-hash", "--no-cpu-baseline", "--no-extra"]
+    hashes = []
+    for extra in (["--gpus", "1"], ["--gpus", "3", "--rehearse-shared-gpu", "--exchange-budget", "20"]):
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + extra + common, capture_output=True, text=True, timeout=900,
+                           env=env, cwd=ROOT)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+        line = json.loads([l for l in r.stdout.splitlines() if l.strip()][-1])
+        assert line["parity"]["ok"] is True and len(line["y_sha256"]) == 64
+        hashes.append(line["y_sha256"])
+    assert hashes[0] == hashes[1]
