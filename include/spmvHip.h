@@ -205,6 +205,13 @@ int spmvHipEnqueueAuto(spmat* dMat, double* dX, double* dY, void* stream);
 /* ... and for the launcher hipSpMVRowsCSR (variant 2) chose: serial-order sums, y bit-identical to sgemvSerial. */
 int spmvHipEnqueueAutoRows(spmat* dMat, double* dX, double* dY, void* stream);
 
+/* 1 when this device adds the lanes of one LDS atomic instruction that meet in an address in ascending lane order and runs a
+ * wavefront's LDS operations in issue order -- measured by a probe kernel against host sums, cached; 0 otherwise, -1 before
+ * spmvHipInit.  The deterministic forms of the two-phase and the stripes kernel give the serial oracle's bits BECAUSE of
+ * this (it is observed behaviour of gfx950, not an ISA promise): hipSpMVRowsCSR's serial-order selection offers them only
+ * where the probe returns 1 and otherwise stays with the kernel that sums a row in one thread. */
+int spmvHipProbeLdsAtomicOrder(void);
+
 /* Kernel variants behind each launcher (for A/B measurement; default = best):
  *   hipSpMVRowsCSR        0 = one thread walks its row in global memory: the plain restatement of
  *                             cudaSpMVRowsCSR (uncoalesced; 5-6x slower, profiles/r01_variants.md)

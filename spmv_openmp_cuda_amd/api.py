@@ -37,7 +37,7 @@ _vp, _sz, _u64, _i = C.c_void_p, C.c_size_t, C.c_uint64, C.c_int
 _SPMV_ARGS = [C.POINTER(spmat), _vp, CONFIG, _vp]
 _sigs = {
     "spmvHipInit": ([_i, _sz, _sz], _i), "spmvHipFinalize": ([], _i), "spmvHipDeviceCount": ([], _i),
-    "spmvHipSetStream": ([_vp], _i), "spmvHipSetSync": ([_i], _i),
+    "spmvHipSetStream": ([_vp], _i), "spmvHipSetSync": ([_i], _i), "spmvHipProbeLdsAtomicOrder": ([], _i),
     "spmvHipLastKernelSeconds": ([], C.c_double),
     "spmvHipLastLaunch": ([C.POINTER(spmvDim3), C.POINTER(spmvDim3)], _i),
     "spmvHipDeviceSynchronize": ([], _i),

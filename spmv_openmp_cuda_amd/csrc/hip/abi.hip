@@ -25,6 +25,7 @@ struct State {
     int         variantWarpCSR = 2;     // 0 wavefront-per-row restatement, 1 LDS-stream kernel (LDS segmented reduction), 2 the fastest
                                         // reduction-order kernel for the matrix (LDS-stream / two-phase / stripes), measured at first use
     int         variantEllRowMajor = 1; // hipSpMVRowsELLNNTransposed: 0 a thread walks its row in global memory, 1 LDS-stream kernel, same sums
+    int         ldsOrder = -1;          // lds_order_probe_kernel: -1 not run yet, 1 lane-ascending + in issue order, 0 anything else
     bool        ellRowLens = true;
     double      lastSeconds = 0;
     spmvDim3    lastGrid{0, 0, 0}, lastBlock{0, 0, 0};
@@ -197,6 +198,24 @@ __global__ __launch_bounds__(256) void csr_to_ell_kernel(uint32_t M, uint32_t K,
         EJ[at] = c < len ? JA[b + c] : 0u;          // padding {0, 0.0} like the loader's calloc
         EA[at] = c < len ? AS[b + c] : 0.0;
     }
+}
+
+// What the deterministic format kernels rest on is measured behaviour of the LDS, not something the ISA manual promises:
+// (a) lanes of ONE ds_add_f64 instruction that meet in an address are added in ascending lane order, (b) the LDS operations
+// of one wavefront execute in issue order.  This probe checks both against sums computed on the host in that order (the
+// values are chosen so that other orders give other bits); the serial-order selection offers the format kernels only
+// where it passes, so the bitwise contract of hipSpMVRowsCSR never depends on the property silently.
+__global__ __launch_bounds__(64) void lds_order_probe_kernel(const double* __restrict__ v, double* __restrict__ out) {
+    __shared__ double acc[4];
+    const uint32_t lane = threadIdx.x;
+    if (lane < 4) acc[lane] = 0.0;
+    __syncthreads();
+    atomicAdd(&acc[0], v[lane]);                     // 64 lanes, one address
+    atomicAdd(&acc[1 + (lane & 1)], v[64 + lane]);   // two addresses, 32 lanes each
+    atomicAdd(&acc[0], v[128 + lane]);               // a second instruction into the first address: behind the first one
+    if (lane % 3 == 0) atomicAdd(&acc[3], v[192 + lane]);   // a sparse lane mask
+    __syncthreads();
+    if (lane < 4) out[lane] = acc[lane];
 }
 
 // one wavefront per row: does any row hold a column smaller than its predecessor?  (the deterministic format kernels add a
@@ -407,6 +426,34 @@ int spmvHipLastLaunch(spmvDim3* grid, spmvDim3* block) {
     return EXIT_SUCCESS;
 }
 int spmvHipDeviceSynchronize(void) { HIP_TRY(hipDeviceSynchronize()); return EXIT_SUCCESS; }
+
+int spmvHipProbeLdsAtomicOrder(void) {
+    if (!ready("spmvHipProbeLdsAtomicOrder")) return -1;
+    if (S.ldsOrder >= 0) return S.ldsOrder;
+    double h[256], expect[4] = {0, 0, 0, 0}, got[4] = {0, 0, 0, 0};
+    for (int i = 0; i < 256; ++i) h[i] = (i % 2 ? -1.0 : 1.0) / (3.0 + 7.0 * i) + (i % 5) * 0x1.0p-20;
+    volatile double a0 = 0, a1 = 0, a2 = 0, a3 = 0;  // (volatile: plain sequential adds, whatever the host compiler would like to do)
+    for (int l = 0; l < 64; ++l) a0 = a0 + h[l];
+    for (int l = 0; l < 64; ++l) { if (l & 1) a2 = a2 + h[64 + l]; else a1 = a1 + h[64 + l]; }
+    for (int l = 0; l < 64; ++l) a0 = a0 + h[128 + l];
+    for (int l = 0; l < 64; l += 3) a3 = a3 + h[192 + l];
+    expect[0] = a0; expect[1] = a1; expect[2] = a2; expect[3] = a3;
+    double *dV = nullptr, *dOut = nullptr;
+    int ok = 0;
+    if (hipMalloc(&dV, sizeof h) == hipSuccess && hipMalloc(&dOut, sizeof got) == hipSuccess &&
+        hipMemcpy(dV, h, sizeof h, hipMemcpyHostToDevice) == hipSuccess) {
+        ok = 1;
+        for (int rep = 0; rep < 4 && ok; ++rep) {    // a few launches: the answer must not depend on timing
+            hipLaunchKernelGGL(lds_order_probe_kernel, dim3(1), dim3(64), 0, S.stream, dV, dOut);
+            if (hipStreamSynchronize(S.stream) != hipSuccess || hipMemcpy(got, dOut, sizeof got, hipMemcpyDeviceToHost) != hipSuccess) { ok = 0; break; }
+            ok = memcmp(got, expect, sizeof got) == 0;
+        }
+    }
+    (void)hipFree(dV); (void)hipFree(dOut);
+    (void)hipGetLastError();
+    S.ldsOrder = ok;
+    return ok;
+}
 
 int spmvHipSetVariant(const char* launcher, int variant) {
     if (!launcher) return EXIT_FAILURE;
@@ -805,7 +852,7 @@ int autoSelect(spmat* dMat, DevMat* d, int serial, double* dX, CONFIG cfg, doubl
         }
         (void)hipFree(dFlag);
         (void)hipGetLastError();
-        if (unsorted) { d->autoPick[serial] = 0; return EXIT_SUCCESS; }
+        if (unsorted || spmvHipProbeLdsAtomicOrder() != 1) { d->autoPick[serial] = 0; return EXIT_SUCCESS; }
     }
     // which formats exist already (the caller's, or the other selection's winner): those are never freed here
     useTiles(d, serial != 0);

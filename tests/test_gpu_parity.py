@@ -647,6 +647,11 @@ def test_auto_launcher_picks_and_remembers(api, oracle):
     de.free()
 
 
+def test_lds_atomics_add_in_lane_order_on_this_device(api):
+    """The property the deterministic kernels rest on, probed directly (and consulted by the serial-order selection)."""
+    assert api.lib.spmvHipProbeLdsAtomicOrder() == 1
+
+
 def test_serial_order_contract_on_rows_with_unsorted_columns(api, oracle):
     """hipSpMVRowsCSR promises ascending-j sums.  Its deterministic format kernels add in ascending COLUMN order, which is
     the same only when the columns of every row ascend; a caller's CSR with shuffled rows must therefore be served by the
