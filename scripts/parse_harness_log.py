@@ -16,7 +16,7 @@ One CSV row per timing line, with the reference tool's column names
 ompSchedKind,ompChunkSize,ompMonotonic,threadNum,ompGrid,blockSize_x..gridSize_z) followed by the columns
 the reference computes later in spreadsheets: GFLOPS = 2*NNZ/timeAvg, GBps (algorithmic CSR bytes
 NNZ*12 + M*12 + N*8 over timeAvg) and rooflineFrac (GBps / 8000).  Lines starting with '#perf' / '#tight'
-(extra lines of this repo's harness) and ANSI colour codes are ignored.
+/ '#auto' (extra lines of this repo's harness) and ANSI colour codes are ignored.
 
 usage: parse_harness_log.py <logfile|-> [--json]
 """
@@ -42,7 +42,7 @@ def parse(lines):
     rows, ctx = [], {}
     for raw in lines:
         line = ANSI.sub("", raw).rstrip("\n")
-        if line.startswith("#perf") or line.startswith("#tight"):
+        if line.startswith(("#perf", "#tight", "#auto")):
             continue
         if line.startswith("#"):
             ctx = {"source": line[1:].strip()}

@@ -35,6 +35,7 @@ def test_harness_log_grammar_and_csv():
 def test_parser_reads_gpu_lines():
     log = ("#A.mtx\\nSpMV_OMP_test.c\\tAVG_TIMES_ITERATION:25\\tsparse matrix: 2597x2597-76367NNZ-62=MAX_ROW_NZ\\n"
            "omp sched gather:\\tkind: OMP_SCHED_DYNAMIC\\tomp chunkSize: 1\\tmonotonic: N\\n"
+           "#auto CSR 0\\tpick:hipSpMVRowsCSR\\tmsStream:0 msTiles:0 msStripes:0 msStripesOrdered:0\\n"
            "\\x1b[1m\\x1b[92m@computing SpMV   with func: CUDA CSR 1 at:0x40d858\\n\\x1b[0m"
            "cudaBlockSize: 256 1 1\\tcudaGridSize: 38 1 1\\t\\ttimeAvg:4.828000e-05 timeVar:4.415998e-13\\t"
            "timeInternalAvg:4.828000e-05 timeInternalVar:4.415998e-13 \\n#perf HIP CSR 1\\tseconds:1e-5\\n").encode().decode("unicode_escape")
