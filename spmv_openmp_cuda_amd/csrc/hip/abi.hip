@@ -205,15 +205,19 @@ __global__ __launch_bounds__(256) void csr_to_ell_kernel(uint32_t M, uint32_t K,
 // of one wavefront execute in issue order.  This probe checks both against sums computed on the host in that order (the
 // values are chosen so that other orders give other bits); the serial-order selection offers the format kernels only
 // where it passes, so the bitwise contract of hipSpMVRowsCSR never depends on the property silently.
-__global__ __launch_bounds__(64) void lds_order_probe_kernel(const double* __restrict__ v, double* __restrict__ out) {
+// (The accumulator of every add is read from memory: with an address the compiler can prove wavefront-uniform its atomic
+// optimizer would replace the 64 adds by a wavefront reduction and ONE add -- another summation order, and not what the
+// SpMV kernels, whose addresses are per-lane rows, execute.)
+__global__ __launch_bounds__(64) void lds_order_probe_kernel(const double* __restrict__ v, const uint32_t* __restrict__ slot,
+                                                             double* __restrict__ out) {
     __shared__ double acc[4];
     const uint32_t lane = threadIdx.x;
     if (lane < 4) acc[lane] = 0.0;
     __syncthreads();
-    atomicAdd(&acc[0], v[lane]);                     // 64 lanes, one address
-    atomicAdd(&acc[1 + (lane & 1)], v[64 + lane]);   // two addresses, 32 lanes each
-    atomicAdd(&acc[0], v[128 + lane]);               // a second instruction into the first address: behind the first one
-    if (lane % 3 == 0) atomicAdd(&acc[3], v[192 + lane]);   // a sparse lane mask
+    atomicAdd(&acc[slot[lane]], v[lane]);                    // 64 lanes, one address
+    atomicAdd(&acc[slot[64 + lane]], v[64 + lane]);          // two addresses, 32 lanes each
+    atomicAdd(&acc[slot[128 + lane]], v[128 + lane]);        // a second instruction into the first address: behind the first one
+    if (slot[192 + lane] < 4) atomicAdd(&acc[slot[192 + lane]], v[192 + lane]);   // a sparse lane mask
     __syncthreads();
     if (lane < 4) out[lane] = acc[lane];
 }
@@ -438,18 +442,21 @@ int spmvHipProbeLdsAtomicOrder(void) {
     for (int l = 0; l < 64; ++l) a0 = a0 + h[128 + l];
     for (int l = 0; l < 64; l += 3) a3 = a3 + h[192 + l];
     expect[0] = a0; expect[1] = a1; expect[2] = a2; expect[3] = a3;
+    uint32_t slot[256];
+    for (int l = 0; l < 64; ++l) { slot[l] = 0; slot[64 + l] = 1 + (l & 1); slot[128 + l] = 0; slot[192 + l] = l % 3 == 0 ? 3 : 99; }
     double *dV = nullptr, *dOut = nullptr;
+    uint32_t* dSlot = nullptr;
     int ok = 0;
-    if (hipMalloc(&dV, sizeof h) == hipSuccess && hipMalloc(&dOut, sizeof got) == hipSuccess &&
-        hipMemcpy(dV, h, sizeof h, hipMemcpyHostToDevice) == hipSuccess) {
+    if (hipMalloc(&dV, sizeof h) == hipSuccess && hipMalloc(&dOut, sizeof got) == hipSuccess && hipMalloc(&dSlot, sizeof slot) == hipSuccess &&
+        hipMemcpy(dV, h, sizeof h, hipMemcpyHostToDevice) == hipSuccess && hipMemcpy(dSlot, slot, sizeof slot, hipMemcpyHostToDevice) == hipSuccess) {
         ok = 1;
         for (int rep = 0; rep < 4 && ok; ++rep) {    // a few launches: the answer must not depend on timing
-            hipLaunchKernelGGL(lds_order_probe_kernel, dim3(1), dim3(64), 0, S.stream, dV, dOut);
+            hipLaunchKernelGGL(lds_order_probe_kernel, dim3(1), dim3(64), 0, S.stream, dV, dSlot, dOut);
             if (hipStreamSynchronize(S.stream) != hipSuccess || hipMemcpy(got, dOut, sizeof got, hipMemcpyDeviceToHost) != hipSuccess) { ok = 0; break; }
             ok = memcmp(got, expect, sizeof got) == 0;
         }
     }
-    (void)hipFree(dV); (void)hipFree(dOut);
+    (void)hipFree(dV); (void)hipFree(dOut); (void)hipFree(dSlot);
     (void)hipGetLastError();
     S.ldsOrder = ok;
     return ok;
