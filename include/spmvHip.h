@@ -120,12 +120,15 @@ SPMV_HIP hipSpMVWarpsPerRowELLNTrasposed; /* <- cudaSpMVWarpsPerRowELLNTrasposed
  * workspace of 8 B/nnz of the largest matrix, shared by all matrices of the
  * device and used in stream order) is built on the device at the first call, or
  * explicitly with spmvHipBuildTiles.  Row sums are added in
- * arrival order (LDS atomics): equal to the oracle to rounding, not bitwise. */
+ * arrival order (LDS atomics): equal to the oracle to rounding, not bitwise -- unless the
+ * deterministic form was asked for with spmvHipBuildTilesOpt (serial order, the oracle's bits;
+ * +4 B/nnz).  The launcher runs the form last asked for (default: arrival order); a handle can
+ * hold both. */
 SPMV_HIP hipSpMVTilesCSR;
 int    spmvHipBuildTiles(spmat* dMat);
 size_t spmvHipTilesBytes(spmat* dMat);
 
-/* One-pass SpMV with y bins in LDS and x served by the XCD's L2 (DESIGN.md section 7b): rows are cut into
+/* One-pass SpMV with y bins in LDS and x served by the XCD's L2 (DESIGN.md section 8): rows are cut into
  * bins of <= 20 000 consecutive rows with equal entry counts, a workgroup owns a bin, and inside a bin the
  * entries are stored in COLUMN order, so that the workgroups resident on one XCD sweep x together and gather
  * from its L2.  12 B/nnz of streaming (fp64 value + {17-bit column offset, 15-bit local row}) and no second
@@ -133,7 +136,8 @@ size_t spmvHipTilesBytes(spmat* dMat);
  * reduction) with the reduction in LDS accumulators.  The copy of the matrix (+12 B/nnz of device memory)
  * is built on the device at the first call or with spmvHipBuildStripes.  Pays off while x (N * 8 B) is small
  * against the entry stream; very wide matrices are the two-phase kernel's.  Row sums are added in arrival
- * order (LDS atomics): equal to the oracle to rounding, not bitwise. */
+ * order (LDS atomics): equal to the oracle to rounding, not bitwise -- unless a deterministic form was asked for with
+ * spmvHipBuildStripesOpt (below).  The launcher runs the form last asked for (default: arrival order). */
 SPMV_HIP hipSpMVStripesCSR;
 int    spmvHipBuildStripes(spmat* dMat);
 size_t spmvHipStripesBytes(spmat* dMat);
