@@ -57,6 +57,41 @@ def test_cli_sharded_env():
     assert np.max(np.abs(y - g["y_csr"])) <= 1e-19
 
 
+def test_cli_at_scale_on_a_generated_matrix(tmp_path, oracle):
+    """The plain-C path end to end on a matrix large enough for everything to matter: a 1 M-row road-network stand-in
+    written as MatrixMarket text (csrc/host/structured.c), read by the CLI's loader (parallel parser), uploaded, run
+    through the reference's mode names -- the two CSR names resolve through the library's selections inside the CLI's
+    single call -- and the dumped y compared with sgemvSerial on the same file (bit for bit for the serial-order modes)."""
+    from spmv_openmp_cuda_amd import api
+    H = api.hostlib
+    mtx = str(tmp_path / "road1m.mtx")
+    Mv, NZv, mx = C.c_ulong(), C.c_ulong(), C.c_ulong()
+    assert H.spmvSynthWriteMtx(mtx.encode(), 1, 1_000_000, 0, 0, 4242, C.byref(Mv), C.byref(NZv), C.byref(mx)) == 0
+    m = H.MMtoCSR(mtx.encode())
+    assert m
+    c = m.contents
+    M, nnz = int(c.M), int(c.NZ)
+    assert nnz >= 1 << 18
+    irp = np.ctypeslib.as_array(c.IRP, shape=(M + 1,)).copy()
+    ja = np.ctypeslib.as_array(c.JA, shape=(nnz,)).copy()
+    as_ = np.ctypeslib.as_array(c.AS, shape=(nnz,)).copy()
+    H.freeSpmat(m)
+    x = np.sin(np.random.default_rng(3).uniform(0, 7, M)) * 3e-5
+    xfile = str(tmp_path / "x.bin")
+    x.tofile(xfile)
+    y_ref = oracle.csr_serial(irp, ja, as_, x)
+    for mode, exact in (("CUDA_CSR_ROWS", True), ("CUDA_CSR_ROWS_WARP", False), ("CUDA_ELL_ROWS", True),
+                        ("CUDA_ELL_ROWS_WARP_NN_TRANSPOSED", False), ("HIP_ELL_ROWS_NN_TRANSPOSED", True)):
+        r = subprocess.run([CLI, mtx, xfile, mode], capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, mode + r.stderr[-2000:]
+        y = np.fromfile("/tmp/outVectorDumpRaw")
+        assert y.size == M and not np.isnan(y).any(), mode
+        assert np.max(np.abs(y - y_ref)) <= 7e-4, mode
+        if exact:
+            assert np.array_equal(y, y_ref + 0.0), mode
+        assert "GFLOPS:" in r.stdout and r.stdout.strip().splitlines()[-1].startswith("cmode:")
+
+
 def test_cli_rejects_bad_usage():
     mtx = os.path.join(GOLD, "cage4like.mtx")
     x = os.path.join(GOLD, "x_cage4like.bin")
