@@ -762,6 +762,13 @@ def test_fuzz_random_shapes(api, oracle, seed):
             assert np.array_equal(y, y_ref), (seed, launcher)
         else:
             assert tight_error(IRP, JA, AS, x, y_ref, y) <= TIGHT, (seed, launcher)
+    if JA.size:
+        # the serial-order forms of the two format kernels on the same odd shapes: the oracle's bits, every one
+        for build, launcher, forms in ((api.build_tiles, "hipSpMVTilesCSR", (1,)), (api.build_stripes, "hipSpMVStripesCSR", (1, 2))):
+            for form in forms:
+                build(dmat, deterministic=form)
+                y = _run(api, launcher, dmat, x, M)
+                assert np.array_equal(y, y_ref), (seed, launcher, form)
     dmat.free()
     if JA.size and int(np.diff(IRP.astype(np.int64)).max()) * M <= 4_000_000:
         for rowlens in (True, False):
