@@ -208,6 +208,24 @@ def test_tiles_reduce_bin_ranges_single_process():
         assert not np.isnan(got[0]).any() and np.all(np.abs(got[0] - y_ref) <= 1e-13 * scale + 1e-300)
         for g in got[1:]:
             assert np.array_equal(g, got[0]), mode
+    # the same two exchange forms on the DETERMINISTIC form of the format: every destination is the serial oracle's bits
+    api.build_tiles(dm, deterministic=True)
+    nbd, rpbd = C.c_uint(), C.c_uint()
+    assert api.lib.spmvHipTilesShape(C.byref(dm.handle), C.byref(nbd), C.byref(rpbd)) == 0 and rpbd.value % 4 == 0
+    for mode in ("fused", "pushk"):
+        for v in big:
+            v.poison()
+        ptrs = [C.c_void_p(v.ptr.value + 8) for v in big]
+        extra = (C.c_void_p * 3)(*[p.value for p in ptrs[1:]])
+        assert api.lib.hipSpMVTilesExpand(C.byref(dm.handle), dx.ptr) == 0
+        if mode == "fused":
+            assert api.lib.hipSpMVTilesReduce(C.byref(dm.handle), 0, nbd.value, ptrs[0], 3, extra) == 0
+        else:
+            assert api.lib.hipSpMVTilesReducePush(C.byref(dm.handle), ptrs[0], 3, extra) == 0
+            assert api.lib.spmvHipTilesPushFailed(C.byref(dm.handle)) == 0
+        for v in big:
+            assert np.array_equal(v.down()[1:], y_ref), mode
+    api.build_tiles(dm)                                       # back to the arrival-order form for the checks below
     assert api.lib.hipSpMVTilesReducePush(C.byref(dm.handle), dy.ptr, 0, None) == 1        # needs a destination
     # invalid ranges fail loudly
     assert api.lib.hipSpMVTilesReduce(C.byref(dm.handle), 2, 1, dy.ptr, 0, None) == 1
