@@ -3,6 +3,7 @@
 #   host     spmv_openmp_cuda_amd/lib/libspmvhost.so, bin/SpMV_HIP.elf     (gcc, plain C host side)
 #   oracle   oracle/liboracle.so (+ oracle/_ref when /root/reference exists) -- checker only
 #   harness  tests/harness/test_SpMV_HIP.elf (links product + oracle; test program)
+#   fuzz     tests/harness/fuzz_loader.elf (host loader + decompressors under ASan/UBSan; test program, not in `all`)
 HIPCC    ?= hipcc
 CC        = gcc
 ARCH     ?= gfx950
@@ -37,7 +38,13 @@ tests/harness/test_SpMV_HIP.elf: tests/harness/spmv_test.c oracle $(PKG)/lib/lib
 	$(CC) $(CFLAGS) -DAVG_TIMES_ITERATION=25 -o $@ tests/harness/spmv_test.c -L$(PKG)/lib -lspmvhost -lspmvhip -Loracle -loracle \
 	    -Wl,-rpath,'$$ORIGIN/../../$(PKG)/lib' -Wl,-rpath,'$$ORIGIN/../../oracle' -lm
 
+# the loader and the decompressors under AddressSanitizer + UBSan (host code only; tests/test_host_side.py runs it)
+fuzz: tests/harness/fuzz_loader.elf
+tests/harness/fuzz_loader.elf: tests/harness/fuzz_loader.c $(HOSTLIBSRC) $(wildcard include/*.h)
+	$(CC) -O1 -g -fopenmp -fsanitize=address,undefined -fno-sanitize-recover=undefined -fno-omit-frame-pointer -Wall -Wextra \
+	    -Wno-unused-parameter -Iinclude -o $@ tests/harness/fuzz_loader.c $(HOSTLIBSRC) -lm -lz -ldl
+
 clean:
 	rm -f $(PKG)/lib/*.so $(PKG)/bin/*.elf tests/harness/*.elf
 	$(MAKE) -C oracle clean
-.PHONY: all lib host oracle harness clean
+.PHONY: all lib host oracle harness fuzz clean

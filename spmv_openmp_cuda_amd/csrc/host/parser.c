@@ -17,6 +17,7 @@
  * releases what it allocated, out-of-range indices are an error.
  */
 #include <ctype.h>
+#include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -84,6 +85,10 @@ int MMCheck(MM_typecode mcode) {
 entry* MMtoCOO(ulong* NZ, FILE* fp, MM_typecode mcode, ulong* rowLens) {
     const int sym = mm_is_symmetric(mcode), pat = mm_is_pattern(mcode);
     const ulong declared = *NZ;
+    if (declared > SIZE_MAX / sizeof(entry) / 2) {     /* e.g. a size line with "-1": %lu wraps it; the products below must not */
+        ERRPRINTS("invalid matrix: %lu entries declared\n", declared);
+        return NULL;
+    }
     const ulong cap = sym ? 2 * declared : declared;
     entry* entries = malloc((cap ? cap : 1) * sizeof *entries);
     if (!entries) { ERRPRINT("MMtoCOO:  entries malloc errd\n"); return NULL; }
@@ -216,8 +221,13 @@ int COOtoCSR(entry* entries, spmat* mat, ulong* rowLens) {
 int COOtoELL(entry* entries, spmat* mat, ulong* rowLens) {
     ulong maxRow = 0;
     for (ulong r = 0; r < mat->M; ++r) maxRow = MAX(maxRow, rowLens[r]);
+    ulong cells;
+    if (__builtin_mul_overflow(mat->M, maxRow, &cells) || cells > SIZE_MAX / sizeof(double) / 2) {
+        ERRPRINTS("MMtoELL:\t%lu rows x %lu slots do not fit the address space\n", mat->M, maxRow);
+        return EXIT_FAILURE;
+    }
 #ifdef LIMIT_ELL_SIZE
-    const ulong ellEntriesTot = 2 * mat->M * maxRow;
+    const ulong ellEntriesTot = 2 * cells;
     if (ellEntriesTot > (ulong)ELL_MAX_ENTRIES) {
         ERRPRINTS("Required entries %lu -> %lu uMB for the matrix exceed the designated threashold of: %lu  -> %lu MB for ellpack\n",
                   ellEntriesTot, (sizeof(double) * ellEntriesTot) >> 20, (ulong)ELL_MAX_ENTRIES,
@@ -225,7 +235,6 @@ int COOtoELL(entry* entries, spmat* mat, ulong* rowLens) {
         return EXIT_FAILURE;
     }
 #endif
-    const ulong cells = mat->M * maxRow;
     mat->AS = calloc(cells ? cells : 1, sizeof *mat->AS);     /* padding = {0.0, col 0} */
     mat->JA = calloc(cells ? cells : 1, sizeof *mat->JA);
     if (!mat->AS || !mat->JA) { ERRPRINT("MMtoELL:\tELL arrays calloc errd\n"); return EXIT_FAILURE; }

@@ -204,7 +204,34 @@ static unsigned char* slurp(const char* path, size_t* len) {
 }
 
 /* .xz: liblzma's single-call buffer decoder, loaded at run time (the image has the library but not its headers).
- * The uncompressed size is not known up front: the output buffer is doubled until the decoder stops asking for more. */
+ * The size of the output comes from the file itself: the stream footer (last 12 bytes: CRC32, backward size, flags,
+ * "YZ") points at the index, whose records hold the uncompressed size of every block (xz file format 1.x, sections 2.1.2
+ * and 4).  A truncated file has no footer and is refused at once -- the decoder's BUF_ERROR does not tell a short input
+ * from a short output buffer, so growing the buffer until it stops complaining never ends for such a file.  One stream
+ * per file, which is what xz and every library writer produce. */
+static int xzVarint(const unsigned char* p, const unsigned char* end, uint64_t* out, const unsigned char** next) {
+    uint64_t v = 0;
+    for (int k = 0; k < 9 && p < end; ++k, ++p) {
+        v |= (uint64_t)(*p & 0x7F) << (7 * k);
+        if (!(*p & 0x80)) { *out = v; *next = p + 1; return 1; }
+    }
+    return 0;
+}
+static int xzUncompressedSize(const unsigned char* in, size_t n, uint64_t* total) {
+    while (n >= 4 && !in[n - 1] && !in[n - 2] && !in[n - 3] && !in[n - 4]) n -= 4;      /* stream padding */
+    if (n < 12 + 12 || in[n - 2] != 'Y' || in[n - 1] != 'Z') return 0;
+    const uint64_t indexSize = ((uint64_t)(in[n - 8] | in[n - 7] << 8 | in[n - 6] << 16 | (uint64_t)in[n - 5] << 24) + 1) * 4;
+    if (indexSize + 12 + 12 > n) return 0;
+    const unsigned char *p = in + n - 12 - indexSize, *end = in + n - 12;
+    uint64_t records, unpadded, size;
+    if (*p++ != 0 || !xzVarint(p, end, &records, &p) || records > indexSize) return 0;
+    *total = 0;
+    for (uint64_t k = 0; k < records; ++k) {
+        if (!xzVarint(p, end, &unpadded, &p) || !xzVarint(p, end, &size, &p) || size > ((uint64_t)1 << 40)) return 0;
+        *total += size;
+    }
+    return 1;
+}
 static int inflateXz(const char* path, FILE* out) {
     void* so = dlopen("liblzma.so.5", RTLD_NOW);
     if (!so) { ERRPRINTS("cannot load liblzma: %s\n", dlerror()); return 1; }
@@ -214,16 +241,17 @@ static int inflateXz(const char* path, FILE* out) {
     unsigned char* in = decode ? slurp(path, &inLen) : NULL;
     int rc = 1;
     if (in) {
-        for (size_t cap = inLen * 8 + (1 << 16); cap <= ((size_t)1 << 36); cap *= 2) {
-            unsigned char* o = malloc(cap);
-            if (!o) break;
+        uint64_t total = 0;
+        unsigned char* o = NULL;
+        if (!xzUncompressedSize(in, inLen, &total)) ERRPRINTS("%s: no xz stream footer / index (truncated file?)\n", path);
+        else if (total > ((uint64_t)1 << 40) || !(o = malloc(total ? (size_t)total : 1))) ERRPRINTS("%s: %lu bytes to inflate\n", path, (ulong)total);
+        else {
             uint64_t memlimit = UINT64_MAX;
             size_t inPos = 0, outPos = 0;
-            const int r = decode(&memlimit, 0, NULL, in, &inPos, inLen, o, &outPos, cap);     /* LZMA_OK = 0, LZMA_BUF_ERROR = 10 */
+            const int r = decode(&memlimit, 0, NULL, in, &inPos, inLen, o, &outPos, (size_t)total);      /* LZMA_OK = 0 */
             if (r == 0) rc = fwrite(o, 1, outPos, out) == outPos ? 0 : 1;
-            free(o);
-            if (r != 10) break;
         }
+        free(o);
         free(in);
     }
     dlclose(so);

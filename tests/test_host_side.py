@@ -347,3 +347,69 @@ def test_compressed_inputs(tmp_path):
     assert H.extractInTmpFS(str(plain).encode(), str(tmp_path / "x").encode()) == -1      # not compressed
     assert H.extractInTmpFS(b"/nonexistent/whatever.mtx.xz", str(tmp_path / "x").encode()) == 1
     assert H.extractInTmpFS(b"/nonexistent/file.mtx.gz", str(tmp_path / "x").encode()) == 1
+
+
+def _archives(tmp_path):
+    import bz2
+    import gzip
+    import lzma
+    import zipfile
+    raw = open(os.path.join(GOLD, "cage4like.mtx"), "rb").read()
+    big = open(os.path.join(GOLD, "rand300.mtx"), "rb").read()
+    out = []
+    for name, data in (("a.mtx.gz", gzip.compress(raw)), ("a.mtx.bz2", bz2.compress(raw)), ("a.mtx.xz", lzma.compress(big))):
+        (tmp_path / name).write_bytes(data)
+        out.append(str(tmp_path / name))
+    for name, method, data in (("a.mtx.zip", zipfile.ZIP_DEFLATED, big), ("s.mtx.zip", zipfile.ZIP_STORED, raw)):
+        with zipfile.ZipFile(tmp_path / name, "w", method) as z:
+            z.writestr("inner.mtx", data)
+        out.append(str(tmp_path / name))
+    return out
+
+
+def test_loader_survives_damaged_files_under_sanitizers(tmp_path):
+    """tests/harness/fuzz_loader.c: thousands of damaged MatrixMarket files and damaged .gz/.bz2/.xz/.zip archives through the
+    host loader built with AddressSanitizer + UBSan; the in-memory parser and the serial fscanf steps must agree on every
+    file (both reject, or the same entries in the same order)."""
+    import subprocess
+    r = subprocess.run(["make", "-s", "fuzz"], cwd=ROOT, capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    work = tmp_path / "work"
+    work.mkdir()
+    env = dict(os.environ, ASAN_OPTIONS="allocator_may_return_null=1", OMP_NUM_THREADS="4")
+    r = subprocess.run([os.path.join(ROOT, "tests/harness/fuzz_loader.elf"), str(work), "6000", "20261005"] + _archives(tmp_path),
+                       capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stdout[-4000:] + r.stderr[-4000:]
+    assert "ERROR: AddressSanitizer" not in r.stderr and "runtime error" not in r.stderr
+    line = r.stdout.strip().splitlines()[-1]
+    nums = [int(t) for t in line.replace(",", " ").replace(";", " ").split() if t.isdigit()]
+    files, accepted, rejected, csr, ell, archives, inflated = nums
+    assert files == 4500 and accepted + rejected == files and accepted > 500 and rejected > 500 and csr == ell > 300
+    assert archives == 1500 and 0 < inflated < archives
+
+
+def test_size_line_that_wraps_and_truncated_xz(tmp_path):
+    """Found by the fuzzer: `%lu` reads "-29" as 2^64-29, and 24 bytes x such a count wraps to a small allocation (now refused
+    before any product is formed); a truncated .xz made the decoder loop double its output buffer up to 64 GiB (liblzma answers
+    BUF_ERROR for missing INPUT as well)."""
+    import lzma
+    import time
+    for count in ("-29", "768614336404564651", "18446744073709551615"):
+        p = tmp_path / "wrap.mtx"
+        p.write_text("%%MatrixMarket matrix coordinate real general\n3 3 " + count + "\n1 1 1.0\n2 2 2.0\n")
+        assert not H.MMtoCSR(str(p).encode())
+        fifo = tmp_path / "wrap.fifo"                                  # the serial path alone (not a regular file)
+        os.mkfifo(fifo)
+        import threading
+        t = threading.Thread(target=lambda: open(fifo, "w").write(p.read_text()))
+        t.start()
+        assert not H.MMtoCSR(str(fifo).encode())
+        t.join()
+        os.remove(fifo)
+    H.extractInTmpFS.argtypes = [C.c_char_p, C.c_char_p]
+    data = lzma.compress(open(os.path.join(GOLD, "rand300.mtx"), "rb").read())
+    src = tmp_path / "cut.mtx.xz"
+    src.write_bytes(data[: len(data) // 2])
+    t0 = time.time()
+    assert H.extractInTmpFS(str(src).encode(), str(tmp_path / "cut.mtx").encode()) != 0
+    assert time.time() - t0 < 5
