@@ -38,6 +38,13 @@ tests/harness/test_SpMV_HIP.elf: tests/harness/spmv_test.c oracle $(PKG)/lib/lib
 	$(CC) $(CFLAGS) -DAVG_TIMES_ITERATION=25 -o $@ tests/harness/spmv_test.c -L$(PKG)/lib -lspmvhost -lspmvhip -Loracle -loracle \
 	    -Wl,-rpath,'$$ORIGIN/../../$(PKG)/lib' -Wl,-rpath,'$$ORIGIN/../../oracle' -lm
 
+# the product library with its HOST side under AddressSanitizer + UBSan (device code untouched); scripts/r03_host_asan.sh
+# loads it into the GPU parity tests through SPMV_LIB
+asan: $(PKG)/lib/libspmvhip_asan.so
+$(PKG)/lib/libspmvhip_asan.so: $(HIPSRC) $(HIPHDR)
+	$(HIPCC) $(HIPFLAGS) -g -Xarch_host -fsanitize=address -Xarch_host -fsanitize=undefined -Xarch_host -fno-omit-frame-pointer \
+	    -shared-libsan -o $@ $(HIPSRC)
+
 # the loader and the decompressors under AddressSanitizer + UBSan (host code only; tests/test_host_side.py runs it)
 fuzz: tests/harness/fuzz_loader.elf
 tests/harness/fuzz_loader.elf: tests/harness/fuzz_loader.c $(HOSTLIBSRC) $(wildcard include/*.h)
@@ -47,4 +54,4 @@ tests/harness/fuzz_loader.elf: tests/harness/fuzz_loader.c $(HOSTLIBSRC) $(wildc
 clean:
 	rm -f $(PKG)/lib/*.so $(PKG)/bin/*.elf tests/harness/*.elf
 	$(MAKE) -C oracle clean
-.PHONY: all lib host oracle harness fuzz clean
+.PHONY: all lib host oracle harness fuzz asan clean

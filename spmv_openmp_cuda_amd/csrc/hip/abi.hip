@@ -410,10 +410,22 @@ int spmvHipInit(int dev, size_t sizeofSpmat, size_t sizeofConfig) {
     return EXIT_SUCCESS;
 }
 
+// the push kernel's side stream (hipSpMVTilesReducePush) with its fork / join events: made on first use, on the device of
+// that moment, and given back by spmvHipFinalize()
+namespace { hipStream_t g_pushSide = nullptr; hipEvent_t g_pushFork = nullptr, g_pushJoin = nullptr; bool g_pushPending = false; }
+
 int spmvHipFinalize(void) {
     if (!S.inited) return EXIT_SUCCESS;
     spmvHipDropCache();
     freeTilesWorkspace();
+    peerFinalize();
+    if (g_pushSide) {
+        (void)hipStreamSynchronize(g_pushSide);
+        (void)hipStreamDestroy(g_pushSide);
+        (void)hipEventDestroy(g_pushFork);
+        (void)hipEventDestroy(g_pushJoin);
+        g_pushSide = nullptr; g_pushFork = g_pushJoin = nullptr; g_pushPending = false;
+    }
     if (S.ev0) (void)hipEventDestroy(S.ev0);
     if (S.ev1) (void)hipEventDestroy(S.ev1);
     S.ev0 = S.ev1 = nullptr;
@@ -1021,8 +1033,6 @@ int hipSpMVTilesReduce(spmat* dMat, unsigned binBegin, unsigned binEnd, double* 
     if (enqueueTilesReduce(d, binBegin, binEnd, dY, nExtra, dExtra, S.stream)) { ERR("hipSpMVTilesReduce: launch failed"); return EXIT_FAILURE; }
     return L.finish("hipSpMVTilesReduce");
 }
-
-namespace { hipStream_t g_pushSide = nullptr; hipEvent_t g_pushFork = nullptr, g_pushJoin = nullptr; bool g_pushPending = false; }
 
 int hipSpMVTilesReducePush(spmat* dMat, double* dY, int nExtra, double* const* dExtra) {
     DevMat* d = tilesReady(dMat, "hipSpMVTilesReducePush");

@@ -79,6 +79,7 @@ int  buildTiles(DevMat* d, const spmvTilesOpts* opts = nullptr); // tiles.hip; e
 void tilesInfo(const DevMat* d, spmvTilesInfo* out);
 void freeTiles(TileFormat* t);
 void useTiles(DevMat* d, bool deterministic);                   // make that form the active one (d->tiles may then be null)
+void peerFinalize();                                            // peer.hip: the copy streams of the push exchange
 void freeTilesWorkspace();                                      // the per-device product workspace (8 B/nnz of the largest matrix)
 int  enqueueTiles(DevMat* d, const double* x, double* y, hipStream_t stream);
 int  enqueueTilesExpand(DevMat* d, const double* x, hipStream_t stream);

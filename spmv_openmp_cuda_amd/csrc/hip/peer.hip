@@ -39,6 +39,18 @@ int ensureSlots(int n) {
 
 }  // namespace
 
+namespace spmvhip {
+void peerFinalize() {
+    for (size_t k = 0; k < P.stream.size(); ++k) {
+        (void)hipStreamSynchronize(P.stream[k]);
+        (void)hipStreamDestroy(P.stream[k]);
+        (void)hipEventDestroy(P.done[k]);
+    }
+    if (P.fence) (void)hipEventDestroy(P.fence);
+    P = PushState{};
+}
+}  // namespace spmvhip
+
 extern "C" {
 
 int spmvHipWindowCreate(size_t bytes, void** dBase, unsigned char handle[SPMV_IPC_HANDLE_BYTES]) {

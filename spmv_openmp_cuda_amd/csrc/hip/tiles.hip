@@ -703,7 +703,9 @@ struct TempBuf {
 // addresses matters when a matrix is processed as several row groups whose products fit the 256 MiB Infinity
 // Cache: the lines are overwritten while still cached instead of being written back to HBM and re-allocated
 // (scripts/microbench_mall.hip: write-then-read of a 128 MiB buffer 6.6 TB/s, of a 2 GiB one 4.9-5.1 TB/s).
-struct ProdWorkspace { double* p = nullptr; void* raw = nullptr; size_t cap = 0; hipEvent_t lastUse = nullptr; hipStream_t lastStream = nullptr; bool used = false; };   // lastStream: where the products were last written or read
+// used: work on the products may be unfinished; lastStream: where it was enqueued (compared, never handed to HIP again --
+// its owner may have destroyed it meanwhile); marked: lastUse was recorded behind that work
+struct ProdWorkspace { double* p = nullptr; void* raw = nullptr; size_t cap = 0; hipEvent_t lastUse = nullptr; hipStream_t lastStream = nullptr; bool used = false, marked = false; };
 static ProdWorkspace g_prod[16];
 
 static ProdWorkspace* prodSlot() {
@@ -717,6 +719,7 @@ static double* prodWorkspace(size_t n, bool grow) {
     if (!w) return nullptr;
     if (n <= w->cap || !grow) return n <= w->cap ? w->p : nullptr;
     (void)hipDeviceSynchronize();                   // nothing may still read the old buffer
+    w->used = w->marked = false;
     if (w->raw) (void)hipFree(w->raw);
     w->p = nullptr; w->raw = nullptr; w->cap = 0;
     if (hipMalloc(&w->raw, n * sizeof(double)) != hipSuccess) { w->raw = nullptr; return nullptr; }
@@ -726,21 +729,42 @@ static double* prodWorkspace(size_t n, bool grow) {
 }
 
 // The workspace is shared by every matrix of the device: a phase 1 must not start before the phase 2 that reads the
-// previous products has finished.  On one stream that is stream order.  When the stream changes (spmvHipSetStream, or
-// two handles driven from two streams) the new stream first waits for everything enqueued on the previous one.
+// previous products has finished.  On one stream that is stream order.  When the stream changes (spmvHipSetStream, two
+// handles driven from two streams, the streams of successive shard objects) the new stream first waits for the event
+// that prodMark() recorded behind the previous use.  The previous STREAM is not touched: by now it may be destroyed, and
+// a HIP call on a dead handle is undefined (it happened to return an error; under the sanitizer build it crashed).
 static int prodHandover(hipStream_t stream) {
     ProdWorkspace* w = prodSlot();
     if (!w) return EXIT_FAILURE;
     if (w->used && w->lastStream != stream) {
-        if (!w->lastUse && hipEventCreateWithFlags(&w->lastUse, hipEventDisableTiming) != hipSuccess) return EXIT_FAILURE;
-        if (hipEventRecord(w->lastUse, w->lastStream) != hipSuccess || hipStreamWaitEvent(stream, w->lastUse, 0) != hipSuccess) {
-            (void)hipGetLastError();                // the previous stream is gone: wait for the device instead
+        if (!w->marked || hipStreamWaitEvent(stream, w->lastUse, 0) != hipSuccess) {
+            (void)hipGetLastError();                // no mark (phase 1 without its phase 2, a use inside a graph capture): wait for the device
             if (hipDeviceSynchronize() != hipSuccess) return EXIT_FAILURE;
         }
     }
     w->lastStream = stream;
     w->used = true;
+    w->marked = false;
     return EXIT_SUCCESS;
+}
+
+// behind the last kernel of a use of the products on `stream`
+static void prodMark(hipStream_t stream) {
+    ProdWorkspace* w = prodSlot();
+    if (!w) return;
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(stream, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) {   // an event recorded inside a capture belongs to the graph
+        (void)hipGetLastError();
+        return;
+    }
+    if (!w->lastUse && hipEventCreateWithFlags(&w->lastUse, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); return; }
+    w->marked = hipEventRecord(w->lastUse, stream) == hipSuccess;
+    if (!w->marked) (void)hipGetLastError();
+}
+
+// after a device synchronise: nothing is pending on the products
+static void prodIdle() {
+    if (ProdWorkspace* w = prodSlot()) w->used = w->marked = false;
 }
 
 void freeTilesWorkspace() {
@@ -867,6 +891,7 @@ int buildTiles(DevMat* d, const spmvTilesOpts* opts) {
     TempBuf payB, sortTmp, tileStart;
     auto fail = [&](const char* what) { fprintf(stderr, "libspmvhip: tiles: %s failed\n", what); return EXIT_FAILURE; };
     PB_TRY(hipDeviceSynchronize());                  // nothing may still use the product workspace of this device
+    prodIdle();
     const auto allocT0 = std::chrono::steady_clock::now();
     const size_t offLcol = (nnz * 8 + 255) / 256 * 256, offLrow = offLcol + (nnz * 2 + 255) / 256 * 256;
     const size_t slabBytes = std::max<size_t>(offLrow + nnz * 2, nnz * sizeof(PbPay));
@@ -1113,7 +1138,9 @@ int enqueueTilesReduce(DevMat* d, uint32_t binBegin, uint32_t binEnd, double* y,
         else
             hipLaunchKernelGGL(pb_reduce_det_kernel<0>, grid, dim3(PD_THREADS), lds, stream, t->bins, t->B, binBegin, binEnd, d->M, t->binPos,
                                t->pidx, prod, t->lrow, y, dst, none);
-        return hipGetLastError() == hipSuccess ? EXIT_SUCCESS : EXIT_FAILURE;
+        const bool launched = hipGetLastError() == hipSuccess;
+        prodMark(stream);
+        return launched ? EXIT_SUCCESS : EXIT_FAILURE;
     }
     if (nExtra)
         hipLaunchKernelGGL(pb_reduce_kernel<1>, grid, dim3(PB_THREADS), (size_t)8 * t->R, stream,
@@ -1121,7 +1148,9 @@ int enqueueTilesReduce(DevMat* d, uint32_t binBegin, uint32_t binEnd, double* y,
     else
         hipLaunchKernelGGL(pb_reduce_kernel<0>, grid, dim3(PB_THREADS), (size_t)8 * t->R, stream,
                            t->bins, binBegin, binEnd, d->M, t->binPos, t->waveTile, t->tl, prod, t->lrow, y, dst, none);
-    return hipGetLastError() == hipSuccess ? EXIT_SUCCESS : EXIT_FAILURE;
+    const bool launched = hipGetLastError() == hipSuccess;
+    prodMark(stream);
+    return launched ? EXIT_SUCCESS : EXIT_FAILURE;
 }
 
 // phase 2 over all bins on `stream` with the push kernel beside it on `side`: `side` first waits for what is enqueued on
@@ -1153,8 +1182,10 @@ int enqueueTilesReducePush(DevMat* d, double* y, int nExtra, double* const* extr
     else
         hipLaunchKernelGGL(pb_reduce_kernel<2>, grid2d((uint64_t)((t->B + 7) / 8) * 8, PB_THREADS), dim3(PB_THREADS), (size_t)8 * t->R, stream,
                            t->bins, 0u, t->B, d->M, t->binPos, t->waveTile, t->tl, prod, t->lrow, y, TileDst{}, sig);
+    const bool launched = hipGetLastError() == hipSuccess;
+    prodMark(stream);
     if (hipEventRecord(evJoin, side) != hipSuccess) return EXIT_FAILURE;          // the caller joins (tilesPushJoin) when it needs y delivered
-    return hipGetLastError() == hipSuccess ? EXIT_SUCCESS : EXIT_FAILURE;
+    return launched ? EXIT_SUCCESS : EXIT_FAILURE;
 }
 
 // 1 when a push kernel of this matrix ever gave up waiting for a bin (synchronises the device)

@@ -987,3 +987,45 @@ def test_tiles_build_options(api, oracle):
     assert api.tiles_info(d3).rowsPerBin == auto.rowsPerBin and api.tiles_info(d3).nBins == auto.nBins
     for d in (dmat, d2, d3):
         d.free()
+
+
+def test_device_memory_comes_back(api, oracle):
+    """Handle lifecycle on the device: upload -> both selections (which build, measure and discard formats) -> every format
+    built explicitly in both of its forms -> SELL, ELL conversions -> host-pointer wrappers (cached device copies) -> free,
+    drop the cache, finalize.  After the first round has loaded the code objects, free device memory must come back every
+    round (the runtime keeps its own pools in 4 MiB pieces, so the number wobbles by a few of those; an array of the matrix
+    left behind per round -- 3 MB at 2 B per entry, 20 MB for a copy of the CSR -- adds up past the tolerance)."""
+    import ctypes as C
+    import torch
+    rng = np.random.default_rng(2026)
+    M = N = 200_000
+    IRP, JA, AS = random_csr(rng, M, N, rng.integers(0, 17, size=M))       # ~1.6 M entries: above the selections' threshold
+    x = _x(rng, N)
+    y_ref = oracle.csr_serial(IRP, JA, AS, x)
+    vp = C.c_void_p
+    free = []
+    for round_ in range(7):
+        host = api.HostCSR(M, N, IRP, JA, AS)
+        d = api.spMatCpyCSR(host)
+        assert np.array_equal(_run(api, "hipSpMVRowsCSR", d, x, M), y_ref)
+        assert tight_error(IRP, JA, AS, x, y_ref, _run(api, "hipSpMVWarpPerRowCSR", d, x, M)) <= TIGHT
+        for det in (False, True):
+            api.build_tiles(d, deterministic=det)
+            assert np.max(np.abs(_run(api, "hipSpMVTilesCSR", d, x, M) - y_ref)) <= GATE
+        for mode in (0, 1, 2):
+            api.build_stripes(d, deterministic=mode)
+            assert np.max(np.abs(_run(api, "hipSpMVStripesCSR", d, x, M) - y_ref)) <= GATE
+        assert np.max(np.abs(_run(api, "hipSpMVRowsSELL", d, x, M) - y_ref)) <= GATE
+        for transposed in (False, True):
+            e = api.csr_to_ell_device(d, transposed)
+            assert np.array_equal(_run(api, "hipSpMVRowsELL" if transposed else "hipSpMVRowsELLNNTransposed", e, x, M), y_ref + 0.0)
+            e.free()
+        y = np.empty(M)
+        assert api.lib.spmvHipRowsCSR(C.byref(host.struct), x.ctypes.data_as(vp), None, y.ctypes.data_as(vp)) == 0
+        assert np.array_equal(y, y_ref)
+        d.free()
+        api.spmvHipFinalize()                                                # cache, workspace, events
+        api.spmvHipInit(0)
+        torch.cuda.synchronize()
+        free.append(torch.cuda.mem_get_info()[0])
+    assert min(free[2:]) >= free[1] - (8 << 20) and free[-1] >= free[1] - (8 << 20), free
