@@ -1029,3 +1029,92 @@ def test_device_memory_comes_back(api, oracle):
         torch.cuda.synchronize()
         free.append(torch.cuda.mem_get_info()[0])
     assert min(free[2:]) >= free[1] - (8 << 20) and free[-1] >= free[1] - (8 << 20), free
+
+
+@pytest.mark.parametrize("name", ["irregular", "ones", "uniform32", "banded", "wide"])
+def test_non_finite_x_stays_in_its_rows(api, oracle, name):
+    """x[0] = NaN, one +inf and one -inf further on.  A row is NaN / +inf / -inf exactly when the serial oracle says so
+    (that class does not depend on the order of the sum) and every other row keeps its usual bound -- in particular no
+    kernel may multiply a padding or filler entry with x[0] (the reference's CSR kernels have none; its ELL kernels do
+    read {0.0, column 0} padding unless the row lengths stop them, which is why ELL is taken with row lengths here)."""
+    M, N, IRP, JA, AS = CASES[name]
+    x = _x(np.random.default_rng(70), N)
+    x[0], x[N // 2], x[N - 1] = np.nan, np.inf, -np.inf
+    with np.errstate(invalid="ignore"):
+        y_ref = oracle.csr_serial(IRP, JA, AS, x)
+    finite = np.isfinite(y_ref)
+    assert (~finite).any() and finite.any()
+    x0 = np.where(np.isfinite(x), x, 0.0)                               # the finite rows see only finite x: usual bounds
+    y0_ref = oracle.csr_serial(IRP, JA, AS, x0)
+    assert np.array_equal(y_ref[finite], y0_ref[finite])
+
+    def check(y, exact, who):
+        assert np.array_equal(np.isnan(y), np.isnan(y_ref)), who
+        inf = np.isinf(y_ref)
+        assert np.array_equal(y[inf], y_ref[inf]), who
+        if exact:
+            assert np.array_equal(y[finite], y_ref[finite]), who
+        else:
+            yz, rz = np.where(finite, y, 0.0), np.where(finite, y0_ref, 0.0)
+            assert np.max(np.abs(yz - rz), initial=0.0) <= GATE and tight_error(IRP, JA, AS, x0, rz, yz) <= TIGHT, who
+
+    host = api.HostCSR(M, N, IRP, JA, AS)
+    d = api.spMatCpyCSR(host)
+    for launcher, variant, exact in (("hipSpMVRowsCSR", 0, True), ("hipSpMVRowsCSR", 1, True), ("hipSpMVWarpPerRowCSR", 0, False),
+                                     ("hipSpMVWarpPerRowCSR", 1, False), ("hipSpMVRowsSELL", -1, False)):
+        if variant >= 0:
+            api.set_variant(launcher, variant)
+        check(_run(api, launcher, d, x, M), exact, (launcher, variant))
+    for det in (False, True):
+        api.build_tiles(d, deterministic=det)
+        check(_run(api, "hipSpMVTilesCSR", d, x, M), det, ("tiles", det))
+    for mode in (0, 1, 2):
+        api.build_stripes(d, deterministic=mode)
+        check(_run(api, "hipSpMVStripesCSR", d, x, M), mode != 0, ("stripes", mode))
+    d.free()
+    ell = host.to_ell(with_row_lens=True)
+    api.lib.spmvHipSetEllRowLens(1)
+    for launcher, mat, exact in (("hipSpMVRowsELL", ell.transpose(), True), ("hipSpMVRowsELLNNTransposed", ell, True),
+                                 ("hipSpMVWarpsPerRowELLNTrasposed", ell, False)):
+        de = api.spMatCpyELL(mat)
+        check(_run(api, launcher, de, x, M), exact, launcher)
+        de.free()
+
+
+@pytest.mark.parametrize("name", ["irregular", "uniform32", "wide"])
+def test_subnormal_products_and_sums(api, oracle, name):
+    """Values scaled so that every product and every row sum is subnormal (|a x| ~ 1e-310): the serial-order kernels stay
+    bit-identical to the oracle -- the fp64 units and the LDS adds (`ds_add_f64`, which the deterministic kernels sum
+    with) keep subnormals -- and the others differ by a few units of the smallest subnormal."""
+    M, N, IRP, JA, AS = CASES[name]
+    AS = AS * 1e-305
+    x = _x(np.random.default_rng(71), N)
+    y_ref = oracle.csr_serial(IRP, JA, AS, x)
+    tiny = np.finfo(np.float64).tiny
+    assert np.max(np.abs(y_ref)) < tiny and np.count_nonzero(y_ref) > M // 2
+    host = api.HostCSR(M, N, IRP, JA, AS)
+    d = api.spMatCpyCSR(host)
+    ulp = 5e-324
+    rowlen = np.diff(IRP.astype(np.int64))
+
+    def check(y, exact, who):
+        if exact:
+            assert np.array_equal(y, y_ref), who
+        else:                                                            # every product exact in its last bit or rounded by <= 1 ulp
+            assert np.all(np.abs(y - y_ref) <= ulp * (rowlen + 1)), who
+    for launcher, variant, exact in (("hipSpMVRowsCSR", 0, True), ("hipSpMVRowsCSR", 1, True), ("hipSpMVWarpPerRowCSR", 0, False),
+                                     ("hipSpMVWarpPerRowCSR", 1, False)):
+        api.set_variant(launcher, variant)
+        check(_run(api, launcher, d, x, M), exact, (launcher, variant))
+    for det in (False, True):
+        api.build_tiles(d, deterministic=det)
+        check(_run(api, "hipSpMVTilesCSR", d, x, M), det, ("tiles", det))
+    for mode in (0, 1, 2):
+        api.build_stripes(d, deterministic=mode)
+        check(_run(api, "hipSpMVStripesCSR", d, x, M), mode != 0, ("stripes", mode))
+    d.free()
+    ell = host.to_ell(with_row_lens=True)
+    for launcher, mat in (("hipSpMVRowsELL", ell.transpose()), ("hipSpMVRowsELLNNTransposed", ell)):
+        de = api.spMatCpyELL(mat)
+        assert np.array_equal(_run(api, launcher, de, x, M), y_ref + 0.0), launcher
+        de.free()
