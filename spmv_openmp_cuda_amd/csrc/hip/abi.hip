@@ -122,6 +122,7 @@ void publish(spmat* h, DevMat* d, ulong M, ulong N, ulong NZ, ulong maxRowNz) {
 struct Launch {
     bool timed;
     Launch(dim3 grid, dim3 block) : timed(S.sync) {
+        (void)hipGetLastError();                    // finish() judges THIS launch, not whatever failed before it
         S.lastGrid = {grid.x, grid.y, grid.z};
         S.lastBlock = {block.x, block.y, block.z};
         if (timed) (void)hipEventRecord(S.ev0, S.stream);

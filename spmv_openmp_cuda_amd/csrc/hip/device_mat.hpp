@@ -103,8 +103,11 @@ inline dim3 grid2d(uint64_t blocks, unsigned threads) {
     return dim3((unsigned)gx, (unsigned)((blocks + gx - 1) / gx), 1);
 }
 
+// a failed call is reported HERE, once: the runtime's sticky last-error is cleared so that the next, unrelated call's
+// hipGetLastError() does not see it (a failed hipMalloc of a format build used to make the next spmvHipVecFill "fail")
 inline bool hipOk(hipError_t e, const char* what) {
     if (e == hipSuccess) return true;
+    (void)hipGetLastError();
     fprintf(stderr, "\33[31m\33[1m\33[44mlibspmvhip: %s\t%s\33[0m\n", what, hipGetErrorString(e));
     return false;
 }

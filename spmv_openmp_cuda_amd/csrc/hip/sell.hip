@@ -190,7 +190,7 @@ __global__ __launch_bounds__(256) void sell_flag_long_kernel(uint64_t n, const I
     if ((uint64_t)IRP[row + 1] - (uint64_t)IRP[row] > SELL_MAX_ROW) perm[p] = row | 0x80000000u;
 }
 
-#define SELL_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { fprintf(stderr, "libspmvhip: sell: %s: %s\n", #expr, hipGetErrorString(e_)); return EXIT_FAILURE; } } while (0)
+#define SELL_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { (void)hipGetLastError(); fprintf(stderr, "libspmvhip: sell: %s: %s\n", #expr, hipGetErrorString(e_)); return EXIT_FAILURE; } } while (0)
 
 struct Tmp {
     void* p = nullptr;
@@ -265,7 +265,7 @@ int buildSell(DevMat* d) {
     if (d->M >= 0x7FFFFFFFull) { fprintf(stderr, "libspmvhip: sell: more than 2^31 rows unsupported\n"); return EXIT_FAILURE; }
     SellFormat* f = new SellFormat;
     const int rc = d->irpBytes == 4 ? buildSellT<uint32_t>(d, f) : buildSellT<uint64_t>(d, f);
-    if (rc) { fprintf(stderr, "libspmvhip: sell: format build failed\n"); freeSell(f); return EXIT_FAILURE; }
+    if (rc) { (void)hipGetLastError(); fprintf(stderr, "libspmvhip: sell: format build failed\n"); freeSell(f); return EXIT_FAILURE; }
     d->sell = f;
     return EXIT_SUCCESS;
 }

@@ -332,7 +332,7 @@ __global__ __launch_bounds__(SB_THREADS) void sb_spmv_kernel(
     }
 }
 
-#define SB_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { fprintf(stderr, "libspmvhip: stripes: %s: %s\n", #expr, hipGetErrorString(e_)); return EXIT_FAILURE; } } while (0)
+#define SB_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { (void)hipGetLastError(); fprintf(stderr, "libspmvhip: stripes: %s: %s\n", #expr, hipGetErrorString(e_)); return EXIT_FAILURE; } } while (0)
 
 struct TempBuf {
     void* p = nullptr;
@@ -491,7 +491,7 @@ int buildStripes(DevMat* d, const spmvStripesOpts* opts) {
     f->grid = std::min<uint32_t>(B, cus);
     f->spread = o.spread >= 0 ? (uint32_t)o.spread : SB_SPREAD;          // (used by the arrival-order launch only)
     const uint64_t nGroups = (uint64_t)B * f->subs;
-    auto fail = [&](const char* what) { fprintf(stderr, "libspmvhip: stripes: %s failed\n", what); freeStripes(f); return EXIT_FAILURE; };
+    auto fail = [&](const char* what) { (void)hipGetLastError(); fprintf(stderr, "libspmvhip: stripes: %s failed\n", what); freeStripes(f); return EXIT_FAILURE; };
     TempBuf keys, keysOut, idx, perm, rowOf, sortTmp, dStart, dOverflow;
     if (hipMalloc(&f->binRow, ((size_t)B + 1) * 4) || hipMalloc(&f->subStep, ((size_t)nGroups + 1) * 4) || dStart.alloc(((size_t)nGroups + 1) * 8) ||
         dOverflow.alloc(4))

@@ -687,7 +687,7 @@ __global__ __launch_bounds__(256) void pb_dupcount_kernel(uint32_t B, uint64_t n
     }
 }
 
-#define PB_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { fprintf(stderr, "libspmvhip: tiles: %s: %s\n", #expr, hipGetErrorString(e_)); return EXIT_FAILURE; } } while (0)
+#define PB_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { (void)hipGetLastError(); fprintf(stderr, "libspmvhip: tiles: %s: %s\n", #expr, hipGetErrorString(e_)); return EXIT_FAILURE; } } while (0)
 
 struct TempBuf {
     void* p = nullptr;
@@ -889,7 +889,7 @@ int buildTiles(DevMat* d, const spmvTilesOpts* opts) {
     // ~90 GB mapped for a 19 GB format, a second of hipMalloc).  rocPRIM's double-buffer interface sorts between the two
     // pairs of buffers without further full-size storage.
     TempBuf payB, sortTmp, tileStart;
-    auto fail = [&](const char* what) { fprintf(stderr, "libspmvhip: tiles: %s failed\n", what); return EXIT_FAILURE; };
+    auto fail = [&](const char* what) { (void)hipGetLastError(); fprintf(stderr, "libspmvhip: tiles: %s failed\n", what); return EXIT_FAILURE; };
     PB_TRY(hipDeviceSynchronize());                  // nothing may still use the product workspace of this device
     prodIdle();
     const auto allocT0 = std::chrono::steady_clock::now();

@@ -1118,3 +1118,129 @@ def test_subnormal_products_and_sums(api, oracle, name):
         de = api.spMatCpyELL(mat)
         assert np.array_equal(_run(api, launcher, de, x, M), y_ref + 0.0), launcher
         de.free()
+
+
+def test_under_device_memory_pressure(api, oracle, capfd):
+    """All but 16 MiB of the device taken by someone else: the reference's two names still answer (their selections skip the
+    formats that cannot be built and fall back to the kernel that needs no memory of its own -- serial order bit-identical
+    as ever), the launchers that NEED a format refuse loudly, and a refused build leaves nothing behind: no device memory,
+    and no sticky HIP error for the next, unrelated call to trip over."""
+    import ctypes as C
+    import torch
+    rng = np.random.default_rng(5)
+    M = N = 400_000
+    IRP, JA, AS = random_csr(rng, M, N, rng.integers(0, 17, size=M))       # 3.2 M entries: a format needs 40-50 MB
+    x = _x(rng, N)
+    y_ref = oracle.csr_serial(IRP, JA, AS, x)
+    host = api.HostCSR(M, N, IRP, JA, AS)
+    d = api.spMatCpyCSR(host)
+    dx, dy = api.DeviceVector(N).up(x), api.DeviceVector(M)
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info()[0]
+    hog = C.c_void_p()
+    assert api.lib.spmvHipMalloc(C.byref(hog), free0 - (16 << 20)) == 0
+    try:
+        for launcher, exact in (("hipSpMVWarpPerRowCSR", False), ("hipSpMVRowsCSR", True)):
+            for _ in range(2):                                           # the selection, then the remembered choice
+                dy.poison()
+                api.spmv(launcher, d, dx, dy)
+                y = dy.down()
+                if exact:
+                    assert np.array_equal(y, y_ref)
+                else:
+                    assert tight_error(IRP, JA, AS, x, y_ref, y) <= TIGHT
+        assert api.lib.spmvHipAutoChoice(C.byref(d.handle), None) == b"hipSpMVWarpPerRowCSR"
+        assert api.lib.spmvHipAutoChoiceRows(C.byref(d.handle), None) == b"hipSpMVRowsCSR"
+        refused = 0
+        for launcher in ("hipSpMVTilesCSR", "hipSpMVStripesCSR", "hipSpMVRowsSELL"):
+            dy.poison()
+            try:
+                api.spmv(launcher, d, dx, dy)                            # (the runtime's own pools may still hold room for one of them)
+                assert np.max(np.abs(dy.down() - y_ref)) <= GATE, launcher
+            except api.SpmvHipError:
+                refused += 1
+            dy.poison()                                                  # a launch + hipGetLastError() inside: must not see the failed hipMalloc
+            assert np.isnan(dy.down()).all()
+        assert refused >= 1 and "allocation" in capfd.readouterr().err
+    finally:
+        api.lib.spmvHipFree(hog)
+    for launcher in ("hipSpMVTilesCSR", "hipSpMVStripesCSR", "hipSpMVRowsSELL"):       # with room again the same handle builds them
+        dy.poison()
+        api.spmv(launcher, d, dx, dy)
+        assert np.max(np.abs(dy.down() - y_ref)) <= GATE
+    d.free(); dx.free(); dy.free()
+
+
+def test_two_phase_products_are_handed_from_stream_to_stream(api, oracle):
+    """Two matrices served by the two-phase kernel share the device's ONE product workspace.  Driven alternately from two
+    non-blocking streams without any synchronisation by the caller, B's phase 1 must wait for A's phase 2 (an event recorded
+    behind every phase 2, tiles.hip prodMark / prodHandover) -- every y of every round is checked.  Then the first stream is
+    DESTROYED and the next call comes from the other one: the library must not touch the dead handle (the host-sanitizer
+    run of round 3 caught exactly that), and a stream created afterwards -- possibly at the same address -- works too."""
+    import ctypes as C
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipStreamCreateWithFlags.argtypes = [C.POINTER(C.c_void_p), C.c_uint]
+    hip.hipStreamDestroy.argtypes = [C.c_void_p]
+    hip.hipStreamSynchronize.argtypes = [C.c_void_p]
+    rng = np.random.default_rng(909)
+    mats = []
+    for M, N, per in ((300_000, 300_000, 24), (200_000, 500_000, 32)):       # 7.2 M and 6.4 M entries: phases of ~50-100 us
+        JA = np.sort(rng.integers(0, N, size=(M, per)), axis=1).astype(np.uint64).ravel()
+        IRP = (np.arange(M + 1, dtype=np.uint64) * per)
+        AS = rng.uniform(-1, 1, size=JA.size)
+        x = _x(rng, N)
+        d = api.spMatCpyCSR(api.HostCSR(M, N, IRP, JA, AS))
+        api.build_tiles(d)
+        mats.append((M, IRP, JA, AS, x, oracle.csr_serial(IRP, JA, AS, x), d, api.DeviceVector(N).up(x), [api.DeviceVector(M) for _ in range(6)]))
+    streams = [C.c_void_p(), C.c_void_p()]
+    for s in streams:
+        assert hip.hipStreamCreateWithFlags(C.byref(s), 1) == 0             # hipStreamNonBlocking
+    cfg = api.CONFIG()
+    tiles = api.SPMV_LAUNCHERS["hipSpMVTilesCSR"]
+
+    def enqueue(k, stream, slot):
+        M, IRP, JA, AS, x, y_ref, d, dx, dys = mats[k]
+        api.lib.spmvHipSetStream(stream)
+        assert tiles(C.byref(d.handle), dx.ptr, cfg, dys[slot].ptr) == 0
+
+    def check(k, slots):
+        M, IRP, JA, AS, x, y_ref, d, dx, dys = mats[k]
+        for slot in slots:
+            y = dys[slot].down()
+            assert not np.isnan(y).any() and tight_error(IRP, JA, AS, x, y_ref, y) <= TIGHT, (k, slot)
+            dys[slot].poison()
+    try:
+        for k in (0, 1):
+            for dy in mats[k][8]:
+                dy.poison()
+        api.lib.spmvHipSetSync(0)
+        for round_ in range(5):
+            for slot in range(6):                                        # A on stream 0, B on stream 1, back to back, nobody waits
+                enqueue(0, streams[0], slot)
+                enqueue(1, streams[1], slot)
+            assert api.lib.spmvHipDeviceSynchronize() == 0
+            check(0, range(6)); check(1, range(6))
+        enqueue(0, streams[0], 0)
+        assert hip.hipStreamSynchronize(streams[0]) == 0 and hip.hipStreamDestroy(streams[0]) == 0
+        dead, streams[0] = streams[0].value, C.c_void_p()
+        enqueue(1, streams[1], 0)                                        # hand-over from a stream that no longer exists
+        enqueue(0, streams[1], 1)
+        assert api.lib.spmvHipDeviceSynchronize() == 0
+        check(0, (0, 1)); check(1, (0,))
+        assert hip.hipStreamCreateWithFlags(C.byref(streams[0]), 1) == 0    # often the address of the one just destroyed
+        print("new stream at the dead one's address:", streams[0].value == dead)
+        enqueue(0, streams[0], 2)
+        enqueue(1, streams[1], 2)
+        assert api.lib.spmvHipDeviceSynchronize() == 0
+        check(0, (2,)); check(1, (2,))
+    finally:
+        api.lib.spmvHipSetStream(None)
+        api.lib.spmvHipSetSync(1)
+        api.lib.spmvHipDeviceSynchronize()
+        for s in streams:
+            if s:
+                hip.hipStreamDestroy(s)
+        for m in mats:
+            m[6].free(); m[7].free()
+            for dy in m[8]:
+                dy.free()
