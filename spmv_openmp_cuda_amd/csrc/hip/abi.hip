@@ -50,6 +50,14 @@ DevMat* descOf(spmat* h, const char* who) {
     return d;
 }
 
+// ... for a launcher: the vectors are raw device pointers whose extent the library cannot know, but a NULL one would be
+// dereferenced by every lane of the kernel -- a GPU page fault, which on a shared node is everybody's problem
+DevMat* descOf(spmat* h, const double* x, const double* y, const char* who) {
+    DevMat* d = descOf(h, who);
+    if (d && (!x || !y)) { ERR("%s: %s is NULL", who, !x ? "x" : "y"); return nullptr; }
+    return d;
+}
+
 // Block table of csr_stream2_kernel: rows packed while nnz <= STREAM_NNZ and rows <= STREAM2_MAX_ROWS;
 // a longer row is a block of its own, flagged, and all such blocks come first (longest first) so that
 // their serial tails overlap the rest of the grid.
@@ -639,7 +647,7 @@ int hipFreeSpmat(spmat* h) {
 // ------------------------------------------------------------------------ launchers
 // enqueue-only entry used by shard.hip (explicit stream, no timing bracket, current device = the matrix')
 int spmvHipEnqueueCSR(spmat* dMat, int warpPerRow, double* dX, double* dY, void* stream) {
-    DevMat* d = descOf(dMat, "spmvHipEnqueueCSR");
+    DevMat* d = descOf(dMat, dX, dY, "spmvHipEnqueueCSR");
     if (!d || d->kind != Kind::CSR) return EXIT_FAILURE;
     if (d->M == 0) return EXIT_SUCCESS;
     hipStream_t keep = S.stream;
@@ -655,7 +663,7 @@ int spmvHipEnqueueCSR(spmat* dMat, int warpPerRow, double* dX, double* dY, void*
 // segmented reduction (variant 1 of hipSpMVWarpPerRowCSR); candidate 0 of the two selections below
 static int streamCSR(spmat* dMat, double* dX, double* dY, bool seq) {
     const char* who = seq ? "hipSpMVRowsCSR" : "hipSpMVWarpPerRowCSR";
-    DevMat* d = descOf(dMat, who);
+    DevMat* d = descOf(dMat, dX, dY, who);
     if (!d) return EXIT_FAILURE;
     if (d->kind != Kind::CSR) { ERR("%s: handle is not CSR", who); return EXIT_FAILURE; }
     if (d->M == 0) return nothingToLaunch(d, nullptr);
@@ -668,7 +676,7 @@ static int streamReduce(spmat* m, double* x, CONFIG, double* y)  { return stream
 
 // the two-phase / stripes launchers on the given FORM of their format (built at the first call)
 static int tilesForm(spmat* dMat, double* dX, double* dY, bool det, const char* who) {
-    DevMat* d = descOf(dMat, who);
+    DevMat* d = descOf(dMat, dX, dY, who);
     if (!d) return EXIT_FAILURE;
     if (d->kind != Kind::CSR) { ERR("%s: handle is not CSR", who); return EXIT_FAILURE; }
     if (d->M == 0 || d->NZ == 0) return nothingToLaunch(d, dY);         // nothing to slice: y = 0
@@ -686,7 +694,7 @@ static int tilesForm(spmat* dMat, double* dX, double* dY, bool det, const char* 
 }
 // mode: 0 arrival order, 1 owner wavefronts (its own layout), 2 ordered tickets (the layout of mode 0)
 static int stripesForm(spmat* dMat, double* dX, double* dY, int mode, const char* who) {
-    DevMat* d = descOf(dMat, who);
+    DevMat* d = descOf(dMat, dX, dY, who);
     if (!d) return EXIT_FAILURE;
     if (d->kind != Kind::CSR) { ERR("%s: handle is not CSR", who); return EXIT_FAILURE; }
     if (d->M == 0 || d->NZ == 0) return nothingToLaunch(d, dY);         // nothing to sweep: y = 0
@@ -712,7 +720,7 @@ static int autoRun(spmat* dMat, double* dX, CONFIG cfg, double* dY, int serial, 
 int hipSpMVRowsCSR(spmat* dMat, double* dX, CONFIG cfg, double* dY) {
     if (S.variantRowsCSR == 2) return autoRun(dMat, dX, cfg, dY, 1, "hipSpMVRowsCSR");
     if (S.variantRowsCSR == 1) return streamSerial(dMat, dX, cfg, dY);
-    DevMat* d = descOf(dMat, "hipSpMVRowsCSR");
+    DevMat* d = descOf(dMat, dX, dY, "hipSpMVRowsCSR");
     if (!d) return EXIT_FAILURE;
     if (d->kind != Kind::CSR) { ERR("hipSpMVRowsCSR: handle is not CSR"); return EXIT_FAILURE; }
     if (d->M == 0) return nothingToLaunch(d, nullptr);
@@ -728,7 +736,7 @@ int hipSpMVRowsCSR(spmat* dMat, double* dX, CONFIG cfg, double* dY) {
 int hipSpMVWarpPerRowCSR(spmat* dMat, double* dX, CONFIG cfg, double* dY) {
     if (S.variantWarpCSR == 2) return autoRun(dMat, dX, cfg, dY, 0, "hipSpMVWarpPerRowCSR");
     if (S.variantWarpCSR == 1) return streamReduce(dMat, dX, cfg, dY);
-    DevMat* d = descOf(dMat, "hipSpMVWarpPerRowCSR");
+    DevMat* d = descOf(dMat, dX, dY, "hipSpMVWarpPerRowCSR");
     if (!d) return EXIT_FAILURE;
     if (d->kind != Kind::CSR) { ERR("hipSpMVWarpPerRowCSR: handle is not CSR"); return EXIT_FAILURE; }
     if (d->M == 0) return nothingToLaunch(d, nullptr);
@@ -780,7 +788,7 @@ size_t spmvHipSellBytes(spmat* dMat) {
 }
 int hipSpMVRowsSELL(spmat* dMat, double* dX, CONFIG cfg, double* dY) {
     (void)cfg;
-    DevMat* d = descOf(dMat, "hipSpMVRowsSELL");
+    DevMat* d = descOf(dMat, dX, dY, "hipSpMVRowsSELL");
     if (!d) return EXIT_FAILURE;
     if (d->kind != Kind::CSR) { ERR("hipSpMVRowsSELL: handle is not CSR (the SELL-C-sigma copy is derived from an uploaded CSR)"); return EXIT_FAILURE; }
     if (d->M == 0) return nothingToLaunch(d, nullptr);
@@ -932,7 +940,7 @@ int autoSelect(spmat* dMat, DevMat* d, int serial, double* dX, CONFIG cfg, doubl
 }  // namespace
 
 static int autoRun(spmat* dMat, double* dX, CONFIG cfg, double* dY, int serial, const char* who) {
-    DevMat* d = descOf(dMat, who);
+    DevMat* d = descOf(dMat, dX, dY, who);
     if (!d) return EXIT_FAILURE;
     if (d->kind != Kind::CSR) { ERR("%s: handle is not CSR", who); return EXIT_FAILURE; }
     if (d->M == 0) return nothingToLaunch(d, nullptr);
@@ -1016,6 +1024,7 @@ int spmvHipTilesBinRow(spmat* dMat, unsigned bin, ulong* firstRow) {
 int hipSpMVTilesExpand(spmat* dMat, double* dX) {
     DevMat* d = tilesReady(dMat, "hipSpMVTilesExpand");
     if (!d) return EXIT_FAILURE;
+    if (!dX) { ERR("hipSpMVTilesExpand: x is NULL"); return EXIT_FAILURE; }
     Launch L(dim3(1), dim3(1024));
     if (enqueueTilesExpand(d, dX, S.stream)) { ERR("hipSpMVTilesExpand: launch failed"); return EXIT_FAILURE; }
     return L.finish("hipSpMVTilesExpand");
@@ -1070,7 +1079,7 @@ int spmvHipTilesPushFailed(spmat* dMat) {
 }
 
 int hipSpMVRowsELL(spmat* dMat, double* dX, CONFIG cfg, double* dY) {
-    DevMat* d = descOf(dMat, "hipSpMVRowsELL");
+    DevMat* d = descOf(dMat, dX, dY, "hipSpMVRowsELL");
     if (!d) return EXIT_FAILURE;
     if (d->kind != Kind::ELL_COLMAJOR) { ERR("hipSpMVRowsELL: expects the transposed (column-major) ELL upload: ellTranspose() + spMatCpyELL()"); return EXIT_FAILURE; }
     if (d->M == 0) return nothingToLaunch(d, nullptr);
@@ -1084,7 +1093,7 @@ int hipSpMVRowsELL(spmat* dMat, double* dX, CONFIG cfg, double* dY) {
 }
 
 int hipSpMVRowsELLNNTransposed(spmat* dMat, double* dX, CONFIG cfg, double* dY) {
-    DevMat* d = descOf(dMat, "hipSpMVRowsELLNNTransposed");
+    DevMat* d = descOf(dMat, dX, dY, "hipSpMVRowsELLNNTransposed");
     if (!d) return EXIT_FAILURE;
     if (d->kind != Kind::ELL_ROWMAJOR) { ERR("hipSpMVRowsELLNNTransposed: expects the row-major ELL upload (no ellTranspose)"); return EXIT_FAILURE; }
     if (d->M == 0) return nothingToLaunch(d, nullptr);
@@ -1100,7 +1109,7 @@ int hipSpMVRowsELLNNTransposed(spmat* dMat, double* dX, CONFIG cfg, double* dY) 
 }
 
 int hipSpMVWarpsPerRowELLNTrasposed(spmat* dMat, double* dX, CONFIG cfg, double* dY) {
-    DevMat* d = descOf(dMat, "hipSpMVWarpsPerRowELLNTrasposed");
+    DevMat* d = descOf(dMat, dX, dY, "hipSpMVWarpsPerRowELLNTrasposed");
     if (!d) return EXIT_FAILURE;
     if (d->kind != Kind::ELL_ROWMAJOR) { ERR("hipSpMVWarpsPerRowELLNTrasposed: expects the row-major ELL upload (no ellTranspose)"); return EXIT_FAILURE; }
     if (d->M == 0) return nothingToLaunch(d, nullptr);

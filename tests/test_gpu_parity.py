@@ -1244,3 +1244,30 @@ def test_two_phase_products_are_handed_from_stream_to_stream(api, oracle):
             m[6].free(); m[7].free()
             for dy in m[8]:
                 dy.free()
+
+
+def test_null_vectors_are_refused_on_the_host(api, capfd):
+    """A NULL x or y would be dereferenced by every lane of a kernel (a GPU page fault); every launcher refuses it before
+    anything is enqueued."""
+    import ctypes as C
+    M, N, IRP, JA, AS = CASES["cage4-shaped"]
+    host = api.HostCSR(M, N, IRP, JA, AS)
+    d = api.spMatCpyCSR(host)
+    ell = host.to_ell()
+    de, det = api.spMatCpyELL(ell), api.spMatCpyELL(ell.transpose())
+    dx, dy = api.DeviceVector(N), api.DeviceVector(M)
+    cfg = api.CONFIG()
+    cases = [(n, d) for n in ("hipSpMVRowsCSR", "hipSpMVWarpPerRowCSR", "hipSpMVTilesCSR", "hipSpMVStripesCSR", "hipSpMVRowsSELL", "hipSpMVAutoCSR")]
+    cases += [("hipSpMVRowsELL", det), ("hipSpMVRowsELLNNTransposed", de), ("hipSpMVWarpsPerRowELLNTrasposed", de)]
+    for variant in (0, 1, 2):
+        api.set_variant("hipSpMVRowsCSR", variant)
+        api.set_variant("hipSpMVWarpPerRowCSR", variant)
+        for name, mat in cases:
+            fn = api.SPMV_LAUNCHERS[name]
+            assert fn(C.byref(mat.handle), None, cfg, dy.ptr) != 0, name
+            assert fn(C.byref(mat.handle), dx.ptr, cfg, None) != 0, name
+    assert "is NULL" in capfd.readouterr().err
+    for stream_fn in (api.lib.spmvHipEnqueueAuto, api.lib.spmvHipEnqueueAutoRows):
+        assert stream_fn(C.byref(d.handle), None, dy.ptr, None) != 0
+        assert stream_fn(C.byref(d.handle), dx.ptr, None, None) != 0
+    d.free(); de.free(); det.free(); dx.free(); dy.free()
