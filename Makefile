@@ -40,7 +40,14 @@ tests/harness/test_SpMV_HIP.elf: tests/harness/spmv_test.c oracle $(PKG)/lib/lib
 
 # the product library with its HOST side under AddressSanitizer + UBSan (device code untouched); scripts/r03_host_asan.sh
 # loads it into the GPU parity tests through SPMV_LIB
-asan: $(PKG)/lib/libspmvhip_asan.so
+asan: $(PKG)/lib/libspmvhip_asan.so $(PKG)/bin/SpMV_HIP_asan.elf
+# the CLI built whole under the sanitizers with ROCm's clang (its ASan runtime is the one the library above links; gcc's is another)
+CLANG ?= /opt/rocm/lib/llvm/bin/clang
+$(PKG)/bin/SpMV_HIP_asan.elf: $(HOSTSRC) $(wildcard include/*.h) $(PKG)/lib/libspmvhip_asan.so
+	mkdir -p $(PKG)/bin
+	$(CLANG) -O1 -g -fopenmp -fsanitize=address,undefined -fno-omit-frame-pointer -shared-libsan -Wall -Wextra -Wno-unused-parameter -Iinclude \
+	    -o $@ $(HOSTSRC) -L$(PKG)/lib -l:libspmvhip_asan.so -Wl,-rpath,'$$ORIGIN/../lib' -Wl,-rpath,/opt/rocm/lib/llvm/lib \
+	    -Wl,-rpath,$(dir $(firstword $(wildcard /opt/rocm/lib/llvm/lib/clang/*/lib/linux/libclang_rt.asan-x86_64.so))) -lm -lz -ldl
 $(PKG)/lib/libspmvhip_asan.so: $(HIPSRC) $(HIPHDR)
 	$(HIPCC) $(HIPFLAGS) -g -Xarch_host -fsanitize=address -Xarch_host -fsanitize=undefined -Xarch_host -fno-omit-frame-pointer \
 	    -shared-libsan -o $@ $(HIPSRC)
