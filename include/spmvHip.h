@@ -29,15 +29,23 @@ extern "C" {
 /* Select device `dev` for the calling thread and check the caller was compiled
  * against the same struct layouts.  Must be called once before anything else. */
 int spmvHipInit(int dev, size_t sizeofSpmat, size_t sizeofConfig);
+/* Gives back everything the library holds on its own account: the cached device copies of the host-pointer wrappers, the
+ * per-device product workspace of the two-phase kernel, its side streams and events.  Handles made by spMatCpy* stay the
+ * caller's to free (hipFreeSpmat).  spmvHipInit() may be called again afterwards. */
 int spmvHipFinalize(void);
 /* number of visible devices, or -1 */
 int spmvHipDeviceCount(void);
 /* Stream (hipStream_t passed as void*) used by all later launches/copies of the
- * calling process; NULL = the default stream. */
+ * calling process; NULL = the default stream.  The library uses a stream only INSIDE the calls made while it is set (or
+ * passed): it may be destroyed afterwards without telling the library (the two-phase kernel's product workspace is handed
+ * from stream to stream through an event recorded behind each use, never through the previous stream). */
 int spmvHipSetStream(void* stream);
-/* (With spmvHipSetSync(0) a launcher whose format exists only enqueues kernels on this stream -- no event, allocation or
- * synchronisation -- so a solver's inner loop can be captured into a HIP graph and replayed:
- * tests/test_gpu_parity.py::test_launchers_capture_into_a_hip_graph.) */
+/* (With spmvHipSetSync(0) a launcher whose format exists only enqueues kernels on this stream -- no allocation, no
+ * synchronisation, no timing events; the two-phase launcher records its one hand-over event unless the stream is being
+ * captured -- so a solver's inner loop can be captured into a HIP graph and replayed:
+ * tests/test_gpu_parity.py::test_launchers_capture_into_a_hip_graph.)
+ * Every launcher checks on the host what it can: the handle (kind, magic), NULL x / y (refused: a NULL would be a GPU page
+ * fault in every lane); the EXTENT of x and y is the caller's promise, as in the reference. */
 /* sync != 0 (default): every SpMV launcher waits for completion before it
  * returns and stores the device time in `ElapsedInternal`-style seconds
  * retrievable with spmvHipLastKernelSeconds() -- the behaviour of the
