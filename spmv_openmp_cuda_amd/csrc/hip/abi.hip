@@ -848,11 +848,13 @@ int spmvHipStripesShape(spmat* dMat, unsigned* nBins, unsigned* rowsPerBin, int*
 //   selection 1, serial order (hipSpMVRowsCSR variant 2): LDS-stream kernel with one thread per row / the deterministic
 //                forms of the two-phase and the stripes kernel -- every candidate adds a row's products in ascending j,
 //                so all of them give the bits of the serial oracle and the choice is invisible in y.
-// Every eligible candidate computes y (one warm-up launch that also builds its format, AUTO_REPS timed ones), the fastest
+// Every eligible candidate computes y (one warm-up launch that also builds its format, then AUTO_REPS timed ones -- one
+// if a launch takes milliseconds), the fastest
 // stays, the formats of the others are released, and the chosen launcher runs once more so that y is its own.  The
 // first call is a normal -- slow -- SpMV and synchronises the stream even in enqueue-only mode.
 namespace {
 constexpr int      AUTO_N = 4, AUTO_REPS = 3;
+constexpr float    AUTO_LONG_MS = 2.0f;                 // a launch this long is timed once
 constexpr uint64_t AUTO_MIN_NNZ = 1ull << 18;        // below this a launch is mostly latency: no private format pays
 constexpr uint64_t AUTO_STRIPES_X_BYTES = 256ull << 20;   // the stripes kernel re-reads x once per XCD and round of bins
 struct AutoCand { const char* name; SPMV_HIP* fn; };
@@ -903,7 +905,7 @@ int autoSelect(spmat* dMat, DevMat* d, int serial, double* dX, CONFIG cfg, doubl
     for (int k = 0; k < AUTO_N; ++k) {
         const int c = order[k];
         if (!eligible[c] || !AUTO_CAND[serial][c].fn) continue;
-        if (best >= 0 && boundMs[c] >= bestMs / AUTO_REPS) { d->autoMs[serial][c] = 0; continue; }
+        if (best >= 0 && boundMs[c] >= bestMs) { d->autoMs[serial][c] = 0; continue; }
         // enqueue-only throughout (the library's own timing events belong to the device of spmvHipInit; this may run on another
         // device's stream, spmvHipEnqueueAuto) and no host round trip inside e0..e1
         S.sync = false;
@@ -912,14 +914,23 @@ int autoSelect(spmat* dMat, DevMat* d, int serial, double* dX, CONFIG cfg, doubl
             (void)hipGetLastError();                                      // ... and must not leave its error behind for the next one
             continue;
         }
-        bool ok = hipEventRecord(e0, S.stream) == hipSuccess;
-        for (int r = 0; ok && r < AUTO_REPS; ++r) ok = AUTO_CAND[serial][c].fn(dMat, dX, cfg, dY) == EXIT_SUCCESS;
-        float ms = 0;
-        ok = ok && hipEventRecord(e1, S.stream) == hipSuccess && hipEventSynchronize(e1) == hipSuccess &&
-             hipEventElapsedTime(&ms, e0, e1) == hipSuccess;
+        // one timed launch; AUTO_REPS - 1 more only when a launch is short enough for its timing to be noisy (on c5 the
+        // LDS-stream candidate takes 31 ms a launch: measuring it three times more costs as much as building the winner's format)
+        float ms = 0, more = 0;
+        bool ok = hipEventRecord(e0, S.stream) == hipSuccess && AUTO_CAND[serial][c].fn(dMat, dX, cfg, dY) == EXIT_SUCCESS &&
+                  hipEventRecord(e1, S.stream) == hipSuccess && hipEventSynchronize(e1) == hipSuccess && hipEventElapsedTime(&ms, e0, e1) == hipSuccess;
+        int reps = 1;
+        if (ok && ms < AUTO_LONG_MS) {
+            ok = hipEventRecord(e0, S.stream) == hipSuccess;
+            for (int r = 1; ok && r < AUTO_REPS; ++r) ok = AUTO_CAND[serial][c].fn(dMat, dX, cfg, dY) == EXIT_SUCCESS;
+            ok = ok && hipEventRecord(e1, S.stream) == hipSuccess && hipEventSynchronize(e1) == hipSuccess &&
+                 hipEventElapsedTime(&more, e0, e1) == hipSuccess;
+            reps = AUTO_REPS;
+        }
         if (!ok) { (void)hipGetLastError(); continue; }
-        d->autoMs[serial][c] = ms / AUTO_REPS;
-        if (best < 0 || ms < bestMs) { best = c; bestMs = ms; }
+        const float perLaunch = (ms + more) / reps;
+        d->autoMs[serial][c] = perLaunch;
+        if (best < 0 || perLaunch < bestMs) { best = c; bestMs = perLaunch; }
     }
     S.sync = wasSync;
     (void)hipEventDestroy(e0);
