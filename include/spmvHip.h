@@ -185,7 +185,7 @@ int spmvHipStripesInfo(spmat* dMat, spmvStripesInfo* info);   /* zeros when the 
  * wins depends on where x lives relative to the caches, DESIGN.md sections 4, 7, 8).  Candidates: hipSpMVWarpPerRowCSR
  * always; from 2^18 entries on hipSpMVTilesCSR and, while x (N * 8 B) fits the 256 MiB Infinity Cache,
  * hipSpMVStripesCSR.  The first call runs every eligible candidate on the caller's x (one launch that also builds its
- * format + 3 timed ones; each leaves the complete y), keeps the fastest and frees the private formats of the others;
+ * format + 3 timed ones, a single one if it takes more than 2 ms; each leaves the complete y), keeps the fastest and frees the private formats of the others;
  * it synchronises the stream even after spmvHipSetSync(0).  Later calls go straight to the chosen launcher.
  * spmvHipAutoChoice: its name (NULL before the first call) and, if msPerCandidate != NULL, the three measured times in
  * ms in the order above (0 = not eligible / not tried; room for FOUR doubles, the fourth stays 0).  Arrival-order sums
