@@ -43,7 +43,9 @@ int spmvHipSetStream(void* stream);
 /* (With spmvHipSetSync(0) a launcher whose format exists only enqueues kernels on this stream -- no allocation, no
  * synchronisation, no timing events; the two-phase launcher records its one hand-over event unless the stream is being
  * captured -- so a solver's inner loop can be captured into a HIP graph and replayed:
- * tests/test_gpu_parity.py::test_launchers_capture_into_a_hip_graph.)
+ * tests/test_gpu_parity.py::test_launchers_capture_into_a_hip_graph.  A captured two-phase launch uses the device's product
+ * workspace whenever the graph is replayed, which the library cannot see: keep replays in stream order with, or
+ * synchronised against, two-phase launches of OTHER streams.)
  * Every launcher checks on the host what it can: the handle (kind, magic), NULL x / y (refused: a NULL would be a GPU page
  * fault in every lane); the EXTENT of x and y is the caller's promise, as in the reference. */
 /* sync != 0 (default): every SpMV launcher waits for completion before it
