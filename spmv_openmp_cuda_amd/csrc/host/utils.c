@@ -78,9 +78,9 @@ double* readDoubleVector(char* fpath, ulong* size) {
             if (!t) { ERRPRINTS("realloc errd to ~~ %lu MB\n", (cap * sizeof *out) >> 20); free(out); fclose(fp); return NULL; }
             out = t;
         }
-        size_t got = fread(out + n, sizeof *out, cap - n, fp);
+        const size_t want = cap - n, got = fread(out + n, sizeof *out, want, fp);
         n += got;
-        if (got == 0) break;
+        if (got < want) break;                       /* end of file or error: no further read on this stream */
     }
     if (ferror(fp)) { ERRPRINT("fread errd\n"); free(out); fclose(fp); return NULL; }
     fclose(fp);
