@@ -746,6 +746,13 @@ STRUCTURED = (
                    "OMP ELL 0 spmvRowsBasicELL": "2.81e-2 s = 6.1 GFLOP/s"}},
     {"name": "road-12M", "kind": 1, "p": (12_000_000, 0, 0), "after": "asia_osm (11.95 M rows, 25.4 M nnz, max row 9)",
      "published": {"CUDA CSR 0 (thread per row)": "2.13e-3 s = 23.87 GFLOP/s", "OMP CSR 1 spmvRowsBasicCSR": "3.09e-2 s = 1.6 GFLOP/s"}},
+    # the two graphs above are distributed as MatrixMarket PATTERN files (DIMACS10 collection): the loader gives every entry
+    # 1.0 (parser.c:59-61).  The same shapes written as pattern files: the upload recognises "all values equal" and the CSR
+    # kernels stream no values (include/spmvHip.h, spmvHipSetUnitValues)
+    {"name": "stencil3d-500x100x100-pattern", "kind": 0, "pattern": True, "p": (500, 100, 100), "after": "channel-500x100x100-b050 as distributed: a pattern file",
+     "published": {"CUDA ELL 0 (transposed, thread per row)": "3.86e-3 s = 44.25 GFLOP/s"}},
+    {"name": "road-12M-pattern", "kind": 1, "pattern": True, "p": (12_000_000, 0, 0), "after": "asia_osm as distributed: a pattern file",
+     "published": {"CUDA CSR 0 (thread per row)": "2.13e-3 s = 23.87 GFLOP/s"}},
     {"name": "blocks-36k", "kind": 2, "p": (36_417, 24, 0), "after": "pdb1HYS (36 417 rows, 4.34 M nnz, max row 204)",
      "published": {"CUDA CSR 0 (thread per row)": "1.04e-3 s = 8.4 GFLOP/s", "CUDA CSR 1 (warp per row)": "8.92e-5 s = 97.42 GFLOP/s (INVALID: rows 0..31 only)"}},
 )
@@ -788,7 +795,8 @@ def measure_structured(api, synth, torch, args, steps, warmup, only=""):
         dms = []
         try:
             t0 = time.perf_counter()
-            if H.spmvSynthWriteMtx(path.encode(), spec["kind"], p0, p1, p2, 0x57A7 + spec["kind"], C.byref(Mv), C.byref(NZv), C.byref(mxv)):
+            pattern = bool(spec.get("pattern"))
+            if H.spmvSynthWriteMtx(path.encode(), spec["kind"] | (16 if pattern else 0), p0, p1, p2, 0x57A7 + spec["kind"], C.byref(Mv), C.byref(NZv), C.byref(mxv)):
                 raise RuntimeError("spmvSynthWriteMtx failed")
             t1 = time.perf_counter()
             csr = H.MMtoCSR(path.encode())
@@ -816,6 +824,8 @@ def measure_structured(api, synth, torch, args, steps, warmup, only=""):
             b_csr = synth.algorithmic_bytes_csr(nnz, M, M)
             b_ell = M * K * 12 + M * 8 + M * 8
             blk["algorithmic_bytes"] = {"B_csr = B_ell_rl": b_csr, "B_ell (all slots)": b_ell}
+            if pattern:
+                blk["algorithmic_bytes"]["B_csr without the value stream"] = b_csr - nnz * 8
             x = torch.from_numpy(x_host).cuda()
             y = torch.full((M,), float("nan"), dtype=torch.float64, device="cuda")
 
@@ -839,6 +849,8 @@ def measure_structured(api, synth, torch, args, steps, warmup, only=""):
                      "kernel_ms_avg": k_avg, "kernel_ms_var": k_var, "gflops": 2.0 * nnz / (k_avg * 1e-3) * 1e-9,
                      "bytes_convention": "B_csr" if nbytes == b_csr else "B_ell", "hbm_gbps": nbytes / (k_avg * 1e-3) * 1e-9,
                      "hbm_frac": nbytes / (k_avg * 1e-3) / HBM_PEAK, "parity": par}
+                if pattern and r["bytes_convention"] == "B_csr":
+                    r["hbm_frac_without_value_stream"] = (b_csr - nnz * 8) / (k_avg * 1e-3) / HBM_PEAK
                 if launcher == "hipSpMVRowsCSR" and variant == 2:
                     nm = api.lib.spmvHipAutoChoiceRows(C.byref(mat.handle), None)
                     r["resolved_to"] = nm.decode() if nm else None
@@ -858,6 +870,10 @@ def measure_structured(api, synth, torch, args, steps, warmup, only=""):
             dm.rows = M
             dms.append(dm)
             blk["spMatCpyCSR_s"] = time.perf_counter() - t4
+            uv = C.c_double(0.0)
+            blk["all_values_equal"] = {"recognised": api.lib.spmvHipUnitValue(C.byref(dm.handle), C.byref(uv)) == 1, "value": uv.value}
+            if pattern and not blk["all_values_equal"]["recognised"]:
+                raise SystemExit(f"{spec['name']}: a pattern file was not recognised as an all-values-equal matrix")
             run("CSR thread per row, as named by the reference (hipSpMVRowsCSR, default: fastest serial-order kernel)", "hipSpMVRowsCSR", dm, b_csr, 2, bitwise=True)
             run("CSR thread per row, LDS-stream kernel", "hipSpMVRowsCSR", dm, b_csr, 1, bitwise=True)
             run("CSR wavefront per row, as named by the reference (hipSpMVWarpPerRowCSR, default: fastest reduction-order kernel)", "hipSpMVWarpPerRowCSR", dm, b_csr, 2)
@@ -865,7 +881,8 @@ def measure_structured(api, synth, torch, args, steps, warmup, only=""):
             run("CSR one wavefront per row (the reference kernel's intent)", "hipSpMVWarpPerRowCSR", dm, b_csr, 0)
             run("CSR two-phase", "hipSpMVTilesCSR", dm, b_csr)
             run("CSR stripes", "hipSpMVStripesCSR", dm, b_csr)
-            run("SELL-C-sigma", "hipSpMVRowsSELL", dm, b_csr)
+            if not pattern:
+                run("SELL-C-sigma", "hipSpMVRowsSELL", dm, b_csr)
             set_rows_variant(api, 1)
             api.set_variant("hipSpMVWarpPerRowCSR", 1)
             dm.free()
@@ -880,10 +897,17 @@ def measure_structured(api, synth, torch, args, steps, warmup, only=""):
             if api.lib.spMatCpyELL(ell_t, C.byref(de_t.handle)):
                 raise RuntimeError("spMatCpyELL (transposed) failed")
             dms.append(de_t)
-            for rl in (True, False):
+            for rl in ((True,) if pattern else (True, False)):
                 run("ELL transposed+pitched, thread per row", "hipSpMVRowsELL", de_t, b_csr if rl else b_ell, rl=rl, bitwise=True)
             de_t.free()
             dms.clear()
+            if pattern:                                   # the row-major ELL family and the CPU passes were measured on the valued twin
+                best = min(blk["runs"], key=lambda r: r["kernel_ms_avg"])
+                blk["fastest"] = {"kernel": best["kernel"], "kernel_ms_avg": best["kernel_ms_avg"], "gflops": best["gflops"],
+                                  "hbm_frac_B_csr": b_csr / (best["kernel_ms_avg"] * 1e-3) / HBM_PEAK,
+                                  "hbm_frac_without_value_stream": (b_csr - nnz * 8) / (best["kernel_ms_avg"] * 1e-3) / HBM_PEAK}
+                out["matrices"].append(blk)
+                continue                                  # (the finally below still frees and removes)
             de = api.DeviceMatrix()
             if api.lib.spMatCpyELL(ell, C.byref(de.handle)):
                 raise RuntimeError("spMatCpyELL failed")

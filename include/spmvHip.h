@@ -265,6 +265,15 @@ int spmvHipSetVariant(const char* launcher, int variant);
 /* Use the RL array for ELL early exit (1, default when RL was uploaded) or walk
  * all MAX_ROW_NZ slots like the reference's cudaSpMVRowsELL (0). */
 int spmvHipSetEllRowLens(int useRowLens);
+/* Matrices whose stored values are ALL THE SAME double -- MatrixMarket `pattern` files, which the loader fills with 1.0
+ * (src/lib/parser.c:59-61): every graph of the DIMACS10 collection, among them asia_osm and channel-500x100x100-b050 of
+ * the reference's report -- are recognised when a CSR matrix is uploaded or adopted (one pass over the values).  The CSR
+ * kernels (LDS-stream, stripes, two-phase) then take the value from a register instead of streaming 8 B per entry: 4 B/nnz
+ * of matrix traffic instead of 12.  y does not change by a bit (c * x[j] rounds as AS[j] * x[j] does).  Compared as bit
+ * patterns.  spmvHipSetUnitValues(0) turns the recognition off for later uploads (A/B); spmvHipUnitValue: 1 and the value,
+ * 0, or -1 for a bad handle. */
+int spmvHipSetUnitValues(int on);
+int spmvHipUnitValue(spmat* dMat, double* value);
 
 /* SPMV_INTERF-compatible wrappers (host vectors in/out, matrix uploaded and
  * cached on first use, keyed by the host spmat address) so the GPU path can sit

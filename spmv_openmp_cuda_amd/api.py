@@ -73,6 +73,7 @@ _sigs = {
     "hipSpMVRowsELL": (_SPMV_ARGS, _i), "hipSpMVRowsELLNNTransposed": (_SPMV_ARGS, _i),
     "hipSpMVWarpsPerRowELLNTrasposed": (_SPMV_ARGS, _i),
     "spmvHipSetVariant": ([C.c_char_p, _i], _i), "spmvHipSetEllRowLens": ([_i], _i),
+    "spmvHipSetUnitValues": ([_i], _i), "spmvHipUnitValue": ([C.POINTER(spmat), C.POINTER(C.c_double)], _i),
     "spmvHipRowsCSR": ([C.POINTER(spmat), _vp, C.POINTER(CONFIG), _vp], _i),
     "spmvHipWarpPerRowCSR": ([C.POINTER(spmat), _vp, C.POINTER(CONFIG), _vp], _i),
     "spmvHipRowsELL": ([C.POINTER(spmat), _vp, C.POINTER(CONFIG), _vp], _i),

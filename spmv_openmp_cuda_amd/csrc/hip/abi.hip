@@ -27,6 +27,7 @@ struct State {
     int         variantEllRowMajor = 1; // hipSpMVRowsELLNNTransposed: 0 a thread walks its row in global memory, 1 LDS-stream kernel, same sums
     int         ldsOrder = -1;          // lds_order_probe_kernel: -1 not run yet, 1 lane-ascending + in issue order, 0 anything else
     bool        ellRowLens = true;
+    bool        unitValues = true;      // look for "every stored value is the same double" at upload (spmvHipSetUnitValues)
     double      lastSeconds = 0;
     spmvDim3    lastGrid{0, 0, 0}, lastBlock{0, 0, 0};
     hipEvent_t  ev0 = nullptr, ev1 = nullptr;
@@ -244,14 +245,71 @@ __global__ __launch_bounds__(256) void csr_unsorted_kernel(uint64_t M, const I* 
     if (bad) atomicOr(flag, 1u);
 }
 
+template <bool SEQ, bool UNIT>
+static void launchStream2T(DevMat* d, double* x, double* y) {
+    if (d->irpBytes == 4)
+        hipLaunchKernelGGL((csr_stream2_kernel<uint32_t, SEQ, UNIT>), grid2d(d->nBlk2, WG_THREADS), dim3(WG_THREADS), 0, S.stream,
+                           d->nBlk2, d->nLong2, d->blkInfo, d->blkBase, static_cast<const uint32_t*>(d->IRP), d->JA, d->AS, d->unitValue, x, y);
+    else
+        hipLaunchKernelGGL((csr_stream2_kernel<uint64_t, SEQ, UNIT>), grid2d(d->nBlk2, WG_THREADS), dim3(WG_THREADS), 0, S.stream,
+                           d->nBlk2, d->nLong2, d->blkInfo, d->blkBase, static_cast<const uint64_t*>(d->IRP), d->JA, d->AS, d->unitValue, x, y);
+}
 template <bool SEQ>
 static void launchStream2(DevMat* d, double* x, double* y) {
-    if (d->irpBytes == 4)
-        hipLaunchKernelGGL((csr_stream2_kernel<uint32_t, SEQ>), grid2d(d->nBlk2, WG_THREADS), dim3(WG_THREADS), 0, S.stream,
-                           d->nBlk2, d->nLong2, d->blkInfo, d->blkBase, static_cast<const uint32_t*>(d->IRP), d->JA, d->AS, x, y);
-    else
-        hipLaunchKernelGGL((csr_stream2_kernel<uint64_t, SEQ>), grid2d(d->nBlk2, WG_THREADS), dim3(WG_THREADS), 0, S.stream,
-                           d->nBlk2, d->nLong2, d->blkInfo, d->blkBase, static_cast<const uint64_t*>(d->IRP), d->JA, d->AS, x, y);
+    if (d->unit) launchStream2T<SEQ, true>(d, x, y); else launchStream2T<SEQ, false>(d, x, y);
+}
+
+// 1 in *flag unless every value has the bit pattern `first` (bit patterns: -0.0 and 0.0, or two NaNs, are different values here)
+__global__ __launch_bounds__(256) void values_differ_kernel(const uint64_t* __restrict__ AS, uint64_t n, uint64_t first, uint32_t* __restrict__ flag) {
+    bool differ = false;
+    for (uint64_t j = linear_block() * 256 + threadIdx.x; j < n; j += (uint64_t)gridDim.x * gridDim.y * 256) differ |= AS[j] != first;
+    if (differ) atomicOr(flag, 1u);
+}
+
+// ELL: every REAL cell (slot < RL[row]) has the bit pattern `first`; padding cells are not looked at
+__global__ __launch_bounds__(256) void ell_values_differ_kernel(uint64_t rows, size_t pitch, int colMajor, const uint64_t* __restrict__ AS,
+                                                                const uint32_t* __restrict__ RL, uint64_t first, uint32_t* __restrict__ flag) {
+    const uint64_t r = linear_block() * 256 + threadIdx.x;
+    if (r >= rows) return;
+    bool differ = false;
+    for (uint32_t i = 0, n = RL[r]; i < n; ++i) differ |= AS[colMajor ? r + (uint64_t)i * pitch : r * pitch + i] != first;
+    if (differ) atomicOr(flag, 1u);
+}
+
+// ... for an ELL upload that has row lengths; `first` = the bits of any real cell (found on the host side of the upload)
+static int detectUnitValuesEll(DevMat* d, bool anyCell, uint64_t first) {
+    d->unit = false;
+    if (!S.unitValues || !anyCell || !d->RL || !d->AS || d->M == 0) return EXIT_SUCCESS;
+    uint32_t differ = 1, *dFlag = nullptr;
+    HIP_TRY(hipMalloc(&dFlag, 4));
+    int rc = EXIT_FAILURE;
+    if (hipOk(hipMemset(dFlag, 0, 4), "hipMemset")) {
+        hipLaunchKernelGGL(ell_values_differ_kernel, grid2d((d->M + 255) / 256, 256), dim3(256), 0, nullptr, d->M, d->pitch,
+                           d->kind == Kind::ELL_COLMAJOR ? 1 : 0, reinterpret_cast<const uint64_t*>(d->AS), d->RL, first, dFlag);
+        if (hipOk(hipGetLastError(), "ell_values_differ_kernel") && hipOk(hipMemcpy(&differ, dFlag, 4, hipMemcpyDeviceToHost), "hipMemcpy")) rc = EXIT_SUCCESS;
+    }
+    (void)hipFree(dFlag);
+    if (rc == EXIT_SUCCESS && !differ) { d->unit = true; memcpy(&d->unitValue, &first, 8); }
+    return rc;
+}
+
+// sets d->unit / d->unitValue from the uploaded values (one pass over AS at upload; off with spmvHipSetUnitValues(0))
+static int detectUnitValues(DevMat* d) {
+    d->unit = false;
+    if (!S.unitValues || d->NZ == 0 || !d->AS) return EXIT_SUCCESS;
+    uint64_t first = 0;
+    uint32_t differ = 1, *dFlag = nullptr;
+    HIP_TRY(hipMemcpy(&first, d->AS, 8, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMalloc(&dFlag, 4));
+    int rc = EXIT_FAILURE;
+    if (hipOk(hipMemset(dFlag, 0, 4), "hipMemset")) {
+        const uint64_t blocks = std::min<uint64_t>((d->NZ + 255) / 256, 256 * 64);
+        hipLaunchKernelGGL(values_differ_kernel, grid2d(blocks, 256), dim3(256), 0, nullptr, reinterpret_cast<const uint64_t*>(d->AS), d->NZ, first, dFlag);
+        if (hipOk(hipGetLastError(), "values_differ_kernel") && hipOk(hipMemcpy(&differ, dFlag, 4, hipMemcpyDeviceToHost), "hipMemcpy")) rc = EXIT_SUCCESS;
+    }
+    (void)hipFree(dFlag);
+    if (rc == EXIT_SUCCESS && !differ) { d->unit = true; memcpy(&d->unitValue, &first, 8); }
+    return rc;
 }
 
 // row-major ELL through the LDS-stream kernel (a row must fit a block): seq = one thread sums a row in ascending slots
@@ -260,9 +318,10 @@ static int launchEllStream(DevMat* d, bool rl, bool seq, double* x, double* y, c
     const uint64_t nBlk = (d->M + rowsPerBlk - 1) / rowsPerBlk;
     const dim3 grid = grid2d(nBlk, WG_THREADS), block(WG_THREADS);
     Launch L(grid, block);
-#define ELL_STREAM(RLV, SEQV) hipLaunchKernelGGL((ell_stream_kernel<RLV, SEQV>), grid, block, 0, S.stream, (uint32_t)d->M, (uint32_t)d->K, \
-                                                 (uint32_t)d->pitch, rowsPerBlk, nBlk, d->JA, d->AS, d->RL, x, y)
-    if (rl) { if (seq) ELL_STREAM(true, true); else ELL_STREAM(true, false); }
+#define ELL_STREAM(RLV, SEQV, ...) hipLaunchKernelGGL((ell_stream_kernel<RLV, SEQV, ##__VA_ARGS__>), grid, block, 0, S.stream, (uint32_t)d->M, (uint32_t)d->K, \
+                                                      (uint32_t)d->pitch, rowsPerBlk, nBlk, d->JA, d->AS, d->RL, x, y, d->unitValue)
+    if (rl && d->unit) { if (seq) ELL_STREAM(true, true, true); else ELL_STREAM(true, false, true); }
+    else if (rl) { if (seq) ELL_STREAM(true, true); else ELL_STREAM(true, false); }
     else    { if (seq) ELL_STREAM(false, true); else ELL_STREAM(false, false); }
 #undef ELL_STREAM
     return L.finish(who);
@@ -328,6 +387,13 @@ static int ellUpload(spmat* m, spmat* dst, bool transposed) {
     if (transposed) rc = uploadPitched(d, m->JA, m->AS, slots, rows, (rows + 63) / 64 * 64, colLimit);
     else            rc = uploadPitched(d, m->JA, m->AS, rows, slots, (slots + 1) / 2 * 2, colLimit);   // (rows stay 16-B aligned; a wider pitch is only padding to stream)
     if (!rc && m->RL) rc = narrowUpload<uint32_t>(&d->RL, m->RL, rows, slots, "RL");
+    if (!rc && m->RL && S.unitValues) {                // first real cell on the host: slot 0 of the first non-empty row
+        ulong r = 0;
+        while (r < rows && m->RL[r] == 0) ++r;
+        uint64_t first = 0;
+        if (r < rows) memcpy(&first, &m->AS[transposed ? r : r * slots], 8);      // host layouts: slot-major (pitch = rows) / row-major (pitch = slots)
+        rc = detectUnitValuesEll(d, r < rows, first);
+    }
     if (rc) { freeDesc(d); return EXIT_FAILURE; }
     publish(dst, d, m->M, m->N, m->NZ, m->MAX_ROW_NZ);
     return EXIT_SUCCESS;
@@ -492,6 +558,13 @@ int spmvHipSetVariant(const char* launcher, int variant) {
     return EXIT_FAILURE;
 }
 int spmvHipSetEllRowLens(int use) { S.ellRowLens = use != 0; return EXIT_SUCCESS; }
+int spmvHipSetUnitValues(int on) { S.unitValues = on != 0; return EXIT_SUCCESS; }
+int spmvHipUnitValue(spmat* dMat, double* value) {
+    DevMat* d = descOf(dMat, "spmvHipUnitValue");
+    if (!d) return -1;
+    if (d->unit && value) *value = d->unitValue;
+    return d->unit ? 1 : 0;
+}
 
 // ------------------------------------------------------------------------ vectors
 int spmvHipVecAlloc(double** dVec, size_t n) {
@@ -556,6 +629,7 @@ int spMatCpyCSR(spmat* m, spmat* dst) {
     }
     if (!rc && m->RL) rc = narrowUpload<uint32_t>(&d->RL, m->RL, m->M, 0xFFFFFFFFul, "RL");
     if (!rc) rc = buildRowBlocks2(d, m->IRP, m->M);
+    if (!rc) rc = detectUnitValues(d);
     if (rc) { freeDesc(d); return EXIT_FAILURE; }
     publish(dst, d, m->M, m->N, m->NZ, 0);
     return EXIT_SUCCESS;
@@ -581,7 +655,7 @@ int spmvHipAdoptCSR(spmat* dst, ulong M, ulong N, ulong NZ, const void* dIRP, in
     d->IRP = const_cast<void*>(dIRP); d->JA = const_cast<uint32_t*>(dJA); d->AS = const_cast<double*>(dAS);
     const int rc2 = irpBytes == 4 ? buildRowBlocks2(d, static_cast<const uint32_t*>(hIRP), M)
                                   : buildRowBlocks2(d, static_cast<const uint64_t*>(hIRP), M);
-    if (rc2) { freeDesc(d); return EXIT_FAILURE; }
+    if (rc2 || detectUnitValues(d)) { freeDesc(d); return EXIT_FAILURE; }
     publish(dst, d, M, N, NZ, 0);
     return EXIT_SUCCESS;
 }
@@ -629,6 +703,7 @@ int spmvHipCsrToEll(spmat* dCsr, int transposed, spmat* dEll) {
         else                  hipLaunchKernelGGL((csr_to_ell_kernel<uint64_t>), grid, dim3(256), 0, S.stream, (uint32_t)rows, (uint32_t)K, d->pitch, transposed, static_cast<const uint64_t*>(c->IRP), c->JA, c->AS, d->JA, d->AS, d->RL);
     }
     if (!hipOk(hipGetLastError(), "csr_to_ell launch") || !hipOk(hipStreamSynchronize(S.stream), "csr_to_ell")) { freeDesc(d); return EXIT_FAILURE; }
+    d->unit = c->unit; d->unitValue = c->unitValue;   // the same values, and row lengths always
     // handle fields follow the reference's conventions (transposed: M = slots, MAX_ROW_NZ = rows)
     if (transposed) publish(dEll, d, K, rows, c->NZ, rows);
     else            publish(dEll, d, rows, c->N, c->NZ, K);
@@ -900,7 +975,9 @@ int autoSelect(spmat* dMat, DevMat* d, int serial, double* dX, CONFIG cfg, doubl
     // Lower bound of a format kernel's time: its bytes per entry at the rate this HBM streams (MI355X_MICROARCH.md: 6.3 TB/s).
     // A candidate whose BOUND is no better than what has already been measured cannot win: its format (12 B/nnz of memory,
     // 12 B/nnz of temporaries) is not built.  Order: no format, 12 B/nnz (stripes), 28 B/nnz (two-phase).
-    const double boundMs[AUTO_N] = {0.0, (double)d->NZ * 28.0 / 6.3e12 * 1e3, (double)d->NZ * 12.0 / 6.3e12 * 1e3, (double)d->NZ * 12.0 / 6.3e12 * 1e3};
+    const double vb = d->unit ? 8.0 : 0.0;           // a matrix whose values are all the same streams no values
+    const double boundMs[AUTO_N] = {0.0, (double)d->NZ * (28.0 - vb) / 6.3e12 * 1e3, (double)d->NZ * (12.0 - vb) / 6.3e12 * 1e3,
+                                    (double)d->NZ * (12.0 - vb) / 6.3e12 * 1e3};
     const int order[AUTO_N] = {0, 2, 3, 1};
     for (int k = 0; k < AUTO_N; ++k) {
         const int c = order[k];
@@ -1098,8 +1175,9 @@ int hipSpMVRowsELL(spmat* dMat, double* dX, CONFIG cfg, double* dY) {
     const dim3 grid = grid2d((d->M + bt - 1) / bt, bt), block(bt);
     Launch L(grid, block);
     const bool rl = S.ellRowLens && d->RL;
-    if (rl) hipLaunchKernelGGL((ell_colmajor_thread<true>), grid, block, 0, S.stream, (uint32_t)d->M, (uint32_t)d->K, d->pitch, d->JA, d->AS, d->RL, dX, dY);
-    else    hipLaunchKernelGGL((ell_colmajor_thread<false>), grid, block, 0, S.stream, (uint32_t)d->M, (uint32_t)d->K, d->pitch, d->JA, d->AS, d->RL, dX, dY);
+    if (rl && d->unit) hipLaunchKernelGGL((ell_colmajor_thread<true, true>), grid, block, 0, S.stream, (uint32_t)d->M, (uint32_t)d->K, d->pitch, d->JA, d->AS, d->RL, dX, dY, d->unitValue);
+    else if (rl) hipLaunchKernelGGL((ell_colmajor_thread<true>), grid, block, 0, S.stream, (uint32_t)d->M, (uint32_t)d->K, d->pitch, d->JA, d->AS, d->RL, dX, dY, 0.0);
+    else         hipLaunchKernelGGL((ell_colmajor_thread<false>), grid, block, 0, S.stream, (uint32_t)d->M, (uint32_t)d->K, d->pitch, d->JA, d->AS, d->RL, dX, dY, 0.0);
     return L.finish("hipSpMVRowsELL");
 }
 

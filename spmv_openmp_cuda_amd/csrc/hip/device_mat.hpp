@@ -42,6 +42,11 @@ struct DevMat {
     uint32_t* RL  = nullptr;
     size_t    pitch = 0;            // ELL pitch in elements (same for JA and AS)
     bool      owns = true;          // false for adopted arrays
+    // every stored value is the same double (MatrixMarket `pattern` files are loaded as all 1.0 -- the graphs of the
+    // reference's report, asia_osm and channel-500x100x100, are such files): found at upload; the CSR kernels then take
+    // the value from a register instead of streaming 8 B per entry.  c * x[j] rounds exactly as AS[j] * x[j] does.
+    bool      unit = false;
+    double    unitValue = 0.0;
     uint64_t  maxRowNnz = 0;
     // row blocks of the LDS-stream kernel (CSR): consecutive rows packed while their nnz <= STREAM_NNZ; a longer row is a
     // block of its own; long rows first, then row order

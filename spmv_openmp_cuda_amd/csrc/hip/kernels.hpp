@@ -33,6 +33,12 @@ __device__ __forceinline__ T stream_load(const T* p) {
     return __builtin_nontemporal_load(p);          // (plain loads: equal or slower everywhere, c2 one-pass 0.345 vs 0.320 ms)
 }
 
+// value j of a matrix: from the stream, or -- UNIT: every stored value is the same double -- from a register
+template <bool UNIT>
+__device__ __forceinline__ double value_at(const double* __restrict__ AS, uint64_t j, double unitValue) {
+    return UNIT ? unitValue : stream_load(AS + j);
+}
+
 // sum over the 64 lanes of a wavefront; result valid in lane 0
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
@@ -114,11 +120,11 @@ constexpr int STREAM_UNROLL = STREAM_NNZ / WG_THREADS;
 //  replaces already runs at ~1 lane/clk/CU.  Not kept)
 constexpr uint32_t STREAM2_MAX_ROWS = 2 * WG_THREADS;     // two row pointers per lane
 
-template <typename I, bool SEQ>
+template <typename I, bool SEQ, bool UNIT>
 __global__ __launch_bounds__(WG_THREADS) void csr_stream2_kernel(
     uint32_t nBlk, uint32_t nLong, const uint4* __restrict__ blkInfo, const uint64_t* __restrict__ blkBase,
     const I* __restrict__ IRP, const uint32_t* __restrict__ JA,
-    const double* __restrict__ AS, const double* __restrict__ x, double* __restrict__ y) {
+    const double* __restrict__ AS, double unitValue, const double* __restrict__ x, double* __restrict__ y) {
     __shared__ double   prod[STREAM_NNZ];
     __shared__ uint16_t rowOff[STREAM2_MAX_ROWS + 1];
     __shared__ double   wpart[WG_THREADS / WAVE];
@@ -147,7 +153,7 @@ __global__ __launch_bounds__(WG_THREADS) void csr_stream2_kernel(
 #pragma unroll
                 for (int u = 0; u < STREAM_UNROLL; ++u) {
                     const uint32_t k = tid + u * WG_THREADS;
-                    if (k < cn) prod[k] = stream_load(AS + c + k) * x[stream_load(JA + c + k)];
+                    if (k < cn) prod[k] = value_at<UNIT>(AS, c + k, unitValue) * x[stream_load(JA + c + k)];
                 }
                 __syncthreads();
                 if (tid == 0)
@@ -162,11 +168,11 @@ __global__ __launch_bounds__(WG_THREADS) void csr_stream2_kernel(
         for (; j + 3 * WG_THREADS < end; j += 4 * WG_THREADS) {
             const uint32_t c0 = stream_load(JA + j), c1 = stream_load(JA + j + WG_THREADS),
                            c2 = stream_load(JA + j + 2 * WG_THREADS), c3 = stream_load(JA + j + 3 * WG_THREADS);
-            const double a0 = stream_load(AS + j), a1 = stream_load(AS + j + WG_THREADS),
-                         a2 = stream_load(AS + j + 2 * WG_THREADS), a3 = stream_load(AS + j + 3 * WG_THREADS);
+            const double a0 = value_at<UNIT>(AS, j, unitValue), a1 = value_at<UNIT>(AS, j + WG_THREADS, unitValue),
+                         a2 = value_at<UNIT>(AS, j + 2 * WG_THREADS, unitValue), a3 = value_at<UNIT>(AS, j + 3 * WG_THREADS, unitValue);
             acc0 += a0 * x[c0]; acc1 += a1 * x[c1]; acc2 += a2 * x[c2]; acc3 += a3 * x[c3];
         }
-        for (; j < end; j += WG_THREADS) acc0 += stream_load(AS + j) * x[stream_load(JA + j)];
+        for (; j < end; j += WG_THREADS) acc0 += value_at<UNIT>(AS, j, unitValue) * x[stream_load(JA + j)];
         double acc = wave_sum((acc0 + acc1) + (acc2 + acc3));
         if (tid % WAVE == 0) wpart[tid / WAVE] = acc;
         __syncthreads();
@@ -188,7 +194,7 @@ __global__ __launch_bounds__(WG_THREADS) void csr_stream2_kernel(
             const uint32_t k = tid + u * WG_THREADS;
             const bool in = k < n;
             col[u] = in ? stream_load(JA + base + k) : 0u;
-            val[u] = in ? stream_load(AS + base + k) : 0.0;
+            val[u] = in ? value_at<UNIT>(AS, base + k, unitValue) : 0.0;
         }
         // rows r0 .. r0+R (R <= 512): two row pointers per lane, the closing one is base+n
         uint32_t rp0 = 0, rp1 = 0;
@@ -240,11 +246,13 @@ __global__ __launch_bounds__(WG_THREADS) void csr_stream2_kernel(
 // reads element i of a 512-byte line in every slot.  USE_RL = stop at the row's
 // own length; otherwise walk all slots incl. the {AS=0,JA=0} padding exactly
 // like the reference kernel does.
-template <bool USE_RL>
+// UNIT (with USE_RL only: padding cells are never touched then): every real cell holds `unitValue`, AS is not read.
+template <bool USE_RL, bool UNIT = false>
 __global__ __launch_bounds__(1024) void ell_colmajor_thread(
     uint32_t rows, uint32_t slots, size_t pitch, const uint32_t* __restrict__ JA,
     const double* __restrict__ AS, const uint32_t* __restrict__ RL,
-    const double* __restrict__ x, double* __restrict__ y) {
+    const double* __restrict__ x, double* __restrict__ y, double unitValue = 0.0) {
+    static_assert(USE_RL || !UNIT, "without row lengths the padding cells {0.0, column 0} are part of the sum");
     const uint64_t gid = linear_block() * blockDim.x + threadIdx.x;
     if (gid >= rows) return;
     const uint32_t row = (uint32_t)gid;
@@ -255,12 +263,12 @@ __global__ __launch_bounds__(1024) void ell_colmajor_thread(
     for (; i + 4 <= n; i += 4, idx += 4 * pitch) {
         const uint32_t c0 = stream_load(JA + idx), c1 = stream_load(JA + idx + pitch),
                        c2 = stream_load(JA + idx + 2 * pitch), c3 = stream_load(JA + idx + 3 * pitch);
-        const double a0 = stream_load(AS + idx), a1 = stream_load(AS + idx + pitch),
-                     a2 = stream_load(AS + idx + 2 * pitch), a3 = stream_load(AS + idx + 3 * pitch);
+        const double a0 = value_at<UNIT>(AS, idx, unitValue), a1 = value_at<UNIT>(AS, idx + pitch, unitValue),
+                     a2 = value_at<UNIT>(AS, idx + 2 * pitch, unitValue), a3 = value_at<UNIT>(AS, idx + 3 * pitch, unitValue);
         const double x0 = x[c0], x1 = x[c1], x2 = x[c2], x3 = x[c3];
         acc += a0 * x0; acc += a1 * x1; acc += a2 * x2; acc += a3 * x3;   // ascending slot order
     }
-    for (; i < n; ++i, idx += pitch) acc += stream_load(AS + idx) * x[stream_load(JA + idx)];
+    for (; i < n; ++i, idx += pitch) acc += value_at<UNIT>(AS, idx, unitValue) * x[stream_load(JA + idx)];
     y[row] = acc;
 }
 
@@ -348,10 +356,12 @@ __global__ __launch_bounds__(256) void ell_rowmajor_group(
 // kernels: bit-identical to them and to the serial oracle) -- hipSpMVRowsELLNNTransposed's default: the row-major
 // thread-per-row kernel is uncoalesced by construction (a lane's loads are a pitch apart), the same sums fed from a
 // coalesced span are not.
-template <bool USE_RL, bool SEQ>
+template <bool USE_RL, bool SEQ, bool UNIT = false>
 __global__ __launch_bounds__(WG_THREADS) void ell_stream_kernel(
     uint32_t rows, uint32_t slots, uint32_t pitch, uint32_t rowsPerBlk, uint64_t nBlk, const uint32_t* __restrict__ JA,
-    const double* __restrict__ AS, const uint32_t* __restrict__ RL, const double* __restrict__ x, double* __restrict__ y) {
+    const double* __restrict__ AS, const uint32_t* __restrict__ RL, const double* __restrict__ x, double* __restrict__ y,
+    double unitValue = 0.0) {
+    static_assert(USE_RL || !UNIT, "without row lengths the padding cells {0.0, column 0} are part of the sum");
     __shared__ double prod[STREAM_NNZ];
     const uint32_t tid = threadIdx.x;
     uint64_t blk = linear_block();
@@ -372,7 +382,7 @@ __global__ __launch_bounds__(WG_THREADS) void ell_stream_kernel(
             const uint32_t k = tid + u * WG_THREADS;
             const bool in = k < n;
             col[u] = in ? stream_load(JA + base + k) : 0u;
-            val[u] = in ? stream_load(AS + base + k) : 0.0;
+            val[u] = in ? value_at<UNIT>(AS, base + k, unitValue) : 0.0;     // (UNIT: padding cells get the value too -- parked, never summed)
         }
         double xv[STREAM_UNROLL];
 #pragma unroll

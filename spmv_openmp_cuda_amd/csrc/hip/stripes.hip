@@ -79,6 +79,8 @@ struct StripeFormat {
     uint64_t  nnz = 0, nSteps = 0;
     bool      wide = false, det = false;            // det: the sub-stream-major layout of the owner-wavefront form
     double*   val = nullptr;                        // [nSteps * 128] sub-stream-major, column order inside a sub-stream, each padded to whole steps
+    bool      unit = false;                         // every value of the matrix is `unitValue` (DevMat::unit): no `val` array, the kernel keeps it in a register
+    double    unitValue = 0.0;
     uint32_t* cr = nullptr;                         // narrow: (column - stepBase) << 15 | local row;  wide: column
     uint16_t* lrowW = nullptr;                      // wide only: local row
     uint32_t* stepBase = nullptr;                   // narrow only: [nSteps] first column of the step
@@ -159,7 +161,7 @@ __global__ __launch_bounds__(256) void sb_scatter_kernel(
     const uint64_t q = (uint64_t)subStep[group] * SB_STEP + (pos - e) + (e < SB_STEP / 2 ? 2 * e : 2 * (e - SB_STEP / 2) + 1);
     const uint32_t j = perm[p];
     const uint32_t lrow = rowOf[j] - binRow[bin];
-    val[q] = AS[j];
+    if (val) val[q] = AS[j];                      // (no value array for a matrix whose values are all the same)
     if (WIDE) {
         cr[q] = col;
         lrowW[q] = (uint16_t)lrow;
@@ -207,8 +209,8 @@ struct SbGather { double x0[SB_DEPTH], x1[SB_DEPTH]; };
 // (default form only: the order in which a bin's entries are added is free there) -- and tickets >= nb for nothing
 // (first = s1: loads clamped, adds skipped).
 struct SbBin { uint32_t s0, s1, nb, off; };
-template <bool WIDE>
-__device__ __forceinline__ void sb_stream(SbStream& s, uint32_t t, const SbBin bn, uint32_t lane,
+template <bool WIDE, bool UNIT>
+__device__ __forceinline__ void sb_stream(SbStream& s, uint32_t t, const SbBin bn, uint32_t lane, double unitValue,
                                           const double* __restrict__ val, const uint32_t* __restrict__ cr,
                                           const uint16_t* __restrict__ lrowW, const uint32_t* __restrict__ stepBase) {
     const uint32_t s1 = bn.s1;
@@ -219,7 +221,8 @@ __device__ __forceinline__ void sb_stream(SbStream& s, uint32_t t, const SbBin b
     for (int u = 0; u < SB_DEPTH; ++u) {
         const uint32_t sc = min(s.first + u, s1 - 1u);
         const uint64_t q = (uint64_t)sc * SB_STEP + 2u * lane;
-        s.v[u] = __builtin_nontemporal_load((const dbl2*)(val + q));
+        if (UNIT) s.v[u] = dbl2{unitValue, unitValue};
+        else      s.v[u] = __builtin_nontemporal_load((const dbl2*)(val + q));
         s.c[u] = __builtin_nontemporal_load((const u32x2*)(cr + q));
         if (WIDE) { s.r[u] = __builtin_nontemporal_load((const u16x2*)(lrowW + q)); s.base[u] = 0; }
         else      { s.base[u] = stepBase[sc]; s.r[u] = u16x2{0, 0}; }
@@ -265,9 +268,9 @@ __device__ __forceinline__ uint32_t sb_ticket(uint32_t* ctr, uint32_t lane) {
 // workgroup in a tight pack gathers no faster, because the gather is bounded by the lines a CU's L1 can have in
 // flight to L2 (~0.27-0.38 lines per clock and CU here and in scripts/microbench_gather.hip), not by L2 misses.
 
-template <bool WIDE, int DET>
+template <bool WIDE, int DET, bool UNIT>
 __global__ __launch_bounds__(SB_THREADS) void sb_spmv_kernel(
-    uint32_t B, const uint32_t* __restrict__ binRow, const uint32_t* __restrict__ subStep,
+    uint32_t B, const uint32_t* __restrict__ binRow, const uint32_t* __restrict__ subStep, double unitValue,
     const double* __restrict__ val, const uint32_t* __restrict__ cr, const uint16_t* __restrict__ lrowW,
     const uint32_t* __restrict__ stepBase, const double* __restrict__ x, double* __restrict__ y, uint32_t ldsRows, uint32_t spread) {
     extern __shared__ double yb[];                  // ldsRows doubles (rows of the highest bin), then the ticket counter
@@ -295,9 +298,9 @@ __global__ __launch_bounds__(SB_THREADS) void sb_spmv_kernel(
         const uint32_t s1 = bn.s1;
         const bool any = s1 > bn.s0;                 // uniform per workgroup (default form) / per wavefront (deterministic form)
         if (any) {                                   // first three batches; moving before the bin is zeroed
-            sb_stream<WIDE>(a, DET == 1 ? 0u : wave, bn, lane, val, cr, lrowW, stepBase);
-            sb_stream<WIDE>(b, DET == 1 ? 1u : wave + SB_WAVES, bn, lane, val, cr, lrowW, stepBase);
-            sb_stream<WIDE>(c, DET == 1 ? 2u : wave + 2 * SB_WAVES, bn, lane, val, cr, lrowW, stepBase);
+            sb_stream<WIDE, UNIT>(a, DET == 1 ? 0u : wave, bn, lane, unitValue, val, cr, lrowW, stepBase);
+            sb_stream<WIDE, UNIT>(b, DET == 1 ? 1u : wave + SB_WAVES, bn, lane, unitValue, val, cr, lrowW, stepBase);
+            sb_stream<WIDE, UNIT>(c, DET == 1 ? 2u : wave + 2 * SB_WAVES, bn, lane, unitValue, val, cr, lrowW, stepBase);
         }
         for (uint32_t k = threadIdx.x; k < R; k += SB_THREADS) yb[k] = 0.0;
         if (DET != 1 && threadIdx.x == 0) { *ctr = 3 * SB_WAVES; *turn = 0; }
@@ -308,7 +311,7 @@ __global__ __launch_bounds__(SB_THREADS) void sb_spmv_kernel(
 #define SB_STAGE(CUR, NXT, FAR, GC, GN)                                                                          \
             if (CUR.first >= s1) break;                                                                          \
             sb_gather<WIDE>(GN, NXT, x);                                                                         \
-            sb_stream<WIDE>(FAR, DET == 1 ? mine++ : sb_ticket(ctr, lane), bn, lane, val, cr, lrowW, stepBase);  \
+            sb_stream<WIDE, UNIT>(FAR, DET == 1 ? mine++ : sb_ticket(ctr, lane), bn, lane, unitValue, val, cr, lrowW, stepBase);  \
             if (DET == 2) {       /* batches add in ticket order: wait for the batch before this one */        \
                 while ((uint32_t)__builtin_amdgcn_readfirstlane((int)*turn) != CUR.tk) __builtin_amdgcn_s_sleep(1); \
             }                                                                                                    \
@@ -379,12 +382,12 @@ int fillFormat(StripeFormat* f, bool wide, uint64_t nnz, unsigned colBits, const
     f->wide = wide;
     (void)hipFree(f->cr); (void)hipFree(f->lrowW); (void)hipFree(f->stepBase);
     f->cr = nullptr; f->lrowW = nullptr; f->stepBase = nullptr;
-    if (!f->val) SB_TRY(hipMalloc(&f->val, std::max<uint64_t>(cells, 1) * 8));
+    if (!f->val && !f->unit) SB_TRY(hipMalloc(&f->val, std::max<uint64_t>(cells, 1) * 8));
     SB_TRY(hipMalloc(&f->cr, std::max<uint64_t>(cells, 1) * 4));
     if (wide) SB_TRY(hipMalloc(&f->lrowW, std::max<uint64_t>(cells, 1) * 2));
     else      SB_TRY(hipMalloc(&f->stepBase, std::max<uint64_t>(f->nSteps, 1) * 4));
     // padding entries: value 0, local row SB_NONE (skipped by the kernel: 0 * x must not turn an Inf/NaN of x into a NaN of y)
-    SB_TRY(hipMemsetAsync(f->val, 0, cells * 8, nullptr));
+    if (f->val) SB_TRY(hipMemsetAsync(f->val, 0, cells * 8, nullptr));
     if (cells) {
         if (wide) {
             SB_TRY(hipMemsetAsync(f->cr, 0, cells * 4, nullptr));
@@ -407,8 +410,12 @@ int fillFormat(StripeFormat* f, bool wide, uint64_t nnz, unsigned colBits, const
 
 template <bool WIDE, int DET>
 void launchSpmv(const StripeFormat* f, const double* x, double* y, hipStream_t stream) {
-    hipLaunchKernelGGL((sb_spmv_kernel<WIDE, DET>), dim3(f->grid), dim3(SB_THREADS), (size_t)8 * f->R + 16, stream, f->B, f->binRow, f->subStep,
-                       f->val, f->cr, f->lrowW, f->stepBase, x, y, f->R, f->spread);
+    if (f->unit)
+        hipLaunchKernelGGL((sb_spmv_kernel<WIDE, DET, true>), dim3(f->grid), dim3(SB_THREADS), (size_t)8 * f->R + 16, stream, f->B, f->binRow, f->subStep,
+                           f->unitValue, f->val, f->cr, f->lrowW, f->stepBase, x, y, f->R, f->spread);
+    else
+        hipLaunchKernelGGL((sb_spmv_kernel<WIDE, DET, false>), dim3(f->grid), dim3(SB_THREADS), (size_t)8 * f->R + 16, stream, f->B, f->binRow, f->subStep,
+                           f->unitValue, f->val, f->cr, f->lrowW, f->stepBase, x, y, f->R, f->spread);
 }
 
 }  // namespace
@@ -486,6 +493,7 @@ int buildStripes(DevMat* d, const spmvStripesOpts* opts) {
     StripeFormat* f = new StripeFormat;
     f->opts = o;
     f->det = o.deterministic == 1;
+    f->unit = d->unit; f->unitValue = d->unitValue;
     f->subs = f->det ? SB_WAVES : 1;
     f->B = B; f->R = R; f->nnz = nnz;
     f->grid = std::min<uint32_t>(B, cus);
@@ -551,15 +559,16 @@ int buildStripes(DevMat* d, const spmvStripesOpts* opts) {
         wide = true;                                  // some step spans >= 2^17 columns: 32-bit columns + 16-bit rows
     }
     // (set at every build: the attribute belongs to the current device, and a process may drive several)
-    if (hipFuncSetAttribute((const void*)sb_spmv_kernel<false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, SB_R_MAX * 8 + 16) ||
-        hipFuncSetAttribute((const void*)sb_spmv_kernel<true, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, SB_R_MAX * 8 + 16) ||
-        hipFuncSetAttribute((const void*)sb_spmv_kernel<false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, SB_R_MAX * 8 + 16) ||
-        hipFuncSetAttribute((const void*)sb_spmv_kernel<true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, SB_R_MAX * 8 + 16) ||
-        hipFuncSetAttribute((const void*)sb_spmv_kernel<false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, SB_R_MAX * 8 + 16) ||
-        hipFuncSetAttribute((const void*)sb_spmv_kernel<true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, SB_R_MAX * 8 + 16))
+    const void* kernels[] = {(const void*)sb_spmv_kernel<false, 0, false>, (const void*)sb_spmv_kernel<true, 0, false>, (const void*)sb_spmv_kernel<false, 1, false>,
+                             (const void*)sb_spmv_kernel<true, 1, false>,  (const void*)sb_spmv_kernel<false, 2, false>, (const void*)sb_spmv_kernel<true, 2, false>,
+                             (const void*)sb_spmv_kernel<false, 0, true>,  (const void*)sb_spmv_kernel<true, 0, true>,  (const void*)sb_spmv_kernel<false, 1, true>,
+                             (const void*)sb_spmv_kernel<true, 1, true>,   (const void*)sb_spmv_kernel<false, 2, true>,  (const void*)sb_spmv_kernel<true, 2, true>};
+    bool attrFailed = false;
+    for (const void* k : kernels) attrFailed |= hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, SB_R_MAX * 8 + 16) != hipSuccess;
+    if (attrFailed)
         return fail("kernel attribute");
     const uint64_t cells = steps * SB_STEP;
-    f->bytes = cells * (f->wide ? 14 : 12) + (f->wide ? 0 : steps * 4) + ((size_t)B + 1) * 4 + ((size_t)nGroups + 1) * 4;
+    f->bytes = cells * ((f->wide ? 14 : 12) - (f->unit ? 8 : 0)) + (f->wide ? 0 : steps * 4) + ((size_t)B + 1) * 4 + ((size_t)nGroups + 1) * 4;
     if (hipEventRecord(ev1, nullptr) != hipSuccess || hipEventSynchronize(ev1) != hipSuccess) return fail("synchronise");
     float ms = 0;
     (void)hipEventElapsedTime(&ms, ev0, ev1);

@@ -243,12 +243,15 @@ constexpr uint32_t P1_STEP  = 2 * PB_THREADS;       // entries one workgroup ste
 struct P1Regs { dbl2 a[P1_DEPTH]; ush2 c[P1_DEPTH]; };
 
 // requires ve - 2 >= first entry of the vector range
+// UNIT: every value of the matrix is `unitValue` (DevMat::unit) -- the 8 B/nnz value stream is not read
+template <bool UNIT>
 __device__ __forceinline__ void p1_load(P1Regs& r, uint32_t p, uint32_t ve, const double* __restrict__ val,
-                                        const uint16_t* __restrict__ lcol) {
+                                        const uint16_t* __restrict__ lcol, double unitValue) {
 #pragma unroll
     for (int u = 0; u < P1_DEPTH; ++u) {
         const uint32_t q = min(p + u * P1_STEP, ve - 2u);
-        r.a[u] = __builtin_nontemporal_load((const dbl2*)(val + q));
+        if (UNIT) r.a[u] = dbl2{unitValue, unitValue};
+        else      r.a[u] = __builtin_nontemporal_load((const dbl2*)(val + q));
         r.c[u] = __builtin_nontemporal_load((const ush2*)(lcol + q));
     }
 }
@@ -266,10 +269,10 @@ __device__ __forceinline__ void p1_store(const P1Regs& r, uint32_t p, uint32_t v
     }
 }
 
-template <bool NT>
+template <bool NT, bool UNIT>
 __global__ __launch_bounds__(PB_THREADS) void pb_expand_kernel(
     const uint3* __restrict__ work, const double* __restrict__ val, const uint16_t* __restrict__ lcol,
-    const double* __restrict__ x, uint64_t N, double* __restrict__ prod) {
+    const double* __restrict__ x, uint64_t N, double* __restrict__ prod, double unitValue) {
     extern __shared__ double xs[];                  // PB_C doubles
     const uint3 w = work[lin_block()];
     const uint32_t begin = w.y, end = w.z;
@@ -291,22 +294,22 @@ __global__ __launch_bounds__(PB_THREADS) void pb_expand_kernel(
             const uint32_t k = threadIdx.x + i * PB_THREADS;
             xv[i] = (col0 + k < N) ? x[col0 + k] : 0.0;
         }
-        if (vec) p1_load(cur, p, ve, val, lcol);
+        if (vec) p1_load<UNIT>(cur, p, ve, val, lcol, unitValue);
 #pragma unroll
         for (uint32_t i = 0; i < PB_C / PB_THREADS; ++i) xs[threadIdx.x + i * PB_THREADS] = xv[i];
     }
     __syncthreads();
 
     // scalar head (at most 63 entries) and tail (at most 1)
-    if (threadIdx.x < vb - begin) { const uint32_t q = begin + threadIdx.x; prod[q] = val[q] * xs[lcol[q]]; }
-    if (threadIdx.x < end - ve)   { const uint32_t q = ve + threadIdx.x;    prod[q] = val[q] * xs[lcol[q]]; }
+    if (threadIdx.x < vb - begin) { const uint32_t q = begin + threadIdx.x; prod[q] = (UNIT ? unitValue : val[q]) * xs[lcol[q]]; }
+    if (threadIdx.x < end - ve)   { const uint32_t q = ve + threadIdx.x;    prod[q] = (UNIT ? unitValue : val[q]) * xs[lcol[q]]; }
 
     if (vec) {
         constexpr uint32_t BATCH = P1_DEPTH * P1_STEP;
         for (; p < ve; p += 2 * BATCH) {
-            p1_load(nxt, p + BATCH, ve, val, lcol);
+            p1_load<UNIT>(nxt, p + BATCH, ve, val, lcol, unitValue);
             p1_store<NT>(cur, p, ve, xs, prod);
-            p1_load(cur, p + 2 * BATCH, ve, val, lcol);
+            p1_load<UNIT>(cur, p + 2 * BATCH, ve, val, lcol, unitValue);
             p1_store<NT>(nxt, p + BATCH, ve, xs, prod);
         }
     }
@@ -1059,8 +1062,10 @@ int buildTiles(DevMat* d, const spmvTilesOpts* opts) {
     PB_TRY(hipDeviceSynchronize());
 
     // (set at every build: the attribute belongs to the current device, and a process may drive several)
-    PB_TRY(hipFuncSetAttribute((const void*)pb_expand_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, PB_C * 8));
-    PB_TRY(hipFuncSetAttribute((const void*)pb_expand_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, PB_C * 8));
+    PB_TRY(hipFuncSetAttribute((const void*)pb_expand_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, PB_C * 8));
+    PB_TRY(hipFuncSetAttribute((const void*)pb_expand_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, PB_C * 8));
+    PB_TRY(hipFuncSetAttribute((const void*)pb_expand_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, PB_C * 8));
+    PB_TRY(hipFuncSetAttribute((const void*)pb_expand_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, PB_C * 8));
     PB_TRY(hipFuncSetAttribute((const void*)pb_reduce_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, PB_R_MAX * 8));
     PB_TRY(hipFuncSetAttribute((const void*)pb_reduce_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, PB_R_MAX * 8));
     PB_TRY(hipFuncSetAttribute((const void*)pb_reduce_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, PB_R_MAX * 8));
@@ -1107,12 +1112,11 @@ int enqueueTilesExpand(DevMat* d, const double* x, hipStream_t stream) {
     double* prod = prodWorkspace(t->nnz, true);      // grows (after a device synchronise) only if it was released meanwhile
     if (!prod || prodHandover(stream)) return EXIT_FAILURE;
     if (t->nWork) {
-        if (t->ntStore)
-            hipLaunchKernelGGL(pb_expand_kernel<true>, grid2d(t->nWork, PB_THREADS), dim3(PB_THREADS), PB_C * 8, stream, t->work, t->val,
-                               t->lcol, x, d->N, prod);
-        else
-            hipLaunchKernelGGL(pb_expand_kernel<false>, grid2d(t->nWork, PB_THREADS), dim3(PB_THREADS), PB_C * 8, stream, t->work, t->val,
-                               t->lcol, x, d->N, prod);
+#define PB_EXPAND(NT, UNIT) hipLaunchKernelGGL((pb_expand_kernel<NT, UNIT>), grid2d(t->nWork, PB_THREADS), dim3(PB_THREADS), PB_C * 8, stream, t->work, \
+                                              t->val, t->lcol, x, d->N, prod, d->unitValue)
+        if (d->unit) { if (t->ntStore) PB_EXPAND(true, true); else PB_EXPAND(false, true); }      // (the format keeps its value array: the slab is
+        else         { if (t->ntStore) PB_EXPAND(true, false); else PB_EXPAND(false, false); }    //  the build's sort buffer; it is just not read)
+#undef PB_EXPAND
     }
     return hipGetLastError() == hipSuccess ? EXIT_SUCCESS : EXIT_FAILURE;
 }

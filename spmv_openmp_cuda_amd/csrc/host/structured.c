@@ -137,6 +137,8 @@ static inline char* putValue(char* p, int k) {
     return p;
 }
 
+#define SPMV_SYNTH_PATTERN 16                       /* or-ed into `kind`: write a pattern file */
+
 double spmvSynthStructuredValue(uint64_t seed, ulong row, ulong col) {
     int k = (int)(mix64(seed + 0xA5A5ull + mix64(row * 0x100000001B3ull ^ col)) % 2046) - 1023;
     if (k >= 0) ++k;                                  /* never 0 */
@@ -148,10 +150,13 @@ static inline int valueK(uint64_t seed, ulong row, ulong col) {
 }
 
 /*
- * Writes the matrix to `path` as "%%MatrixMarket matrix coordinate real general".  p0..p2: kind 0 nx, ny, nz;
+ * Writes the matrix to `path` as "%%MatrixMarket matrix coordinate real general" (kind | SPMV_SYNTH_PATTERN: "pattern
+ * general", no values -- what the graphs of the DIMACS10 collection are distributed as).  p0..p2: kind 0 nx, ny, nz;
  * kind 1 rows; kind 2 rows, block size.  Reports rows, entries and the longest row.  EXIT_SUCCESS / EXIT_FAILURE.
  */
 int spmvSynthWriteMtx(const char* path, int kind, ulong p0, ulong p1, ulong p2, uint64_t seed, ulong* M, ulong* NZ, ulong* maxRow) {
+    const int pattern = (kind & SPMV_SYNTH_PATTERN) != 0;       /* "coordinate pattern general": entries without values (loaded as 1.0) */
+    kind &= ~SPMV_SYNTH_PATTERN;
     gen_t g = {kind, p0, p1, p2, 0, seed};
     if (kind == 0) g.n = p0 * p1 * p2;
     else if (kind == 1 || kind == 2) g.n = p0;
@@ -186,8 +191,9 @@ int spmvSynthWriteMtx(const char* path, int kind, ulong p0, ulong p1, ulong p2, 
             char* p = out + at;
             for (unsigned k = 0; k < n; ++k) {
                 p = putUlong(p, r + 1); *p++ = ' ';
-                p = putUlong(p, cols[k] + 1); *p++ = ' ';
-                p = putValue(p, valueK(seed, r, cols[k])); *p++ = '\n';
+                p = putUlong(p, cols[k] + 1);
+                if (!pattern) { *p++ = ' '; p = putValue(p, valueK(seed, r, cols[k])); }
+                *p++ = '\n';
             }
             at = (size_t)(p - out);
         }
@@ -198,8 +204,8 @@ int spmvSynthWriteMtx(const char* path, int kind, ulong p0, ulong p1, ulong p2, 
     ulong nz = 0, longest = 0;
     for (int b = 0; b < nBlk; ++b) { nz += cnt[b]; if (mx[b] > longest) longest = mx[b]; }
     if (!(fp = fopen(path, "w"))) { perror("spmvSynthWriteMtx fopen"); goto done; }
-    fprintf(fp, "%%%%MatrixMarket matrix coordinate real general\n%% stand-in generated by spmvSynthWriteMtx kind %d (%lu %lu %lu) seed %lu\n%lu %lu %lu\n",
-            kind, p0, p1, p2, (unsigned long)seed, g.n, g.n, nz);
+    fprintf(fp, "%%%%MatrixMarket matrix coordinate %s general\n%% stand-in generated by spmvSynthWriteMtx kind %d (%lu %lu %lu) seed %lu\n%lu %lu %lu\n",
+            pattern ? "pattern" : "real", kind, p0, p1, p2, (unsigned long)seed, g.n, g.n, nz);
     for (int b = 0; b < nBlk; ++b)
         if (len[b] && fwrite(buf[b], 1, len[b], fp) != len[b]) { perror("spmvSynthWriteMtx fwrite"); goto done; }
     if (fclose(fp)) { fp = NULL; perror("spmvSynthWriteMtx fclose"); goto done; }

@@ -1271,3 +1271,101 @@ def test_null_vectors_are_refused_on_the_host(api, capfd):
         assert stream_fn(C.byref(d.handle), None, dy.ptr, None) != 0
         assert stream_fn(C.byref(d.handle), dx.ptr, None, None) != 0
     d.free(); de.free(); det.free(); dx.free(); dy.free()
+
+
+@pytest.mark.parametrize("name", ["irregular", "uniform32", "banded", "wide", "hyper-sparse", "ones"])
+@pytest.mark.parametrize("value", [1.0, -2.5])
+def test_matrices_whose_values_are_all_the_same(api, oracle, name, value):
+    """MatrixMarket `pattern` files are loaded as all 1.0 (parser.c:59-61; the graphs of the reference's report are such
+    files).  The upload recognises "every stored value is the same double"; the LDS-stream, stripes and two-phase kernels
+    then keep the value in a register and stream no values.  y must not change by a bit: the serial-order kernels stay
+    identical to the oracle, every kernel equals what it computes with the recognition switched off, and one differing
+    value anywhere switches it off by itself."""
+    import ctypes as C
+    M, N, IRP, JA, AS = CASES[name]
+    AS = np.full(AS.size, value)
+    x = _x(np.random.default_rng(72), N)
+    y_ref = oracle.csr_serial(IRP, JA, AS, x)
+    c = C.c_double(0.0)
+
+    def run_all(d):
+        out = {}
+        for launcher, variant in (("hipSpMVRowsCSR", 0), ("hipSpMVRowsCSR", 1), ("hipSpMVWarpPerRowCSR", 0), ("hipSpMVWarpPerRowCSR", 1)):
+            api.set_variant(launcher, variant)
+            out[(launcher, variant)] = _run(api, launcher, d, x, M)
+        for det in (False, True):
+            api.build_tiles(d, deterministic=det)
+            out[("tiles", det)] = _run(api, "hipSpMVTilesCSR", d, x, M)
+        for mode in (0, 1, 2):
+            api.build_stripes(d, deterministic=mode)
+            out[("stripes", mode)] = _run(api, "hipSpMVStripesCSR", d, x, M)
+        api.set_variant("hipSpMVRowsCSR", 2)
+        api.set_variant("hipSpMVWarpPerRowCSR", 2)
+        out["CUDA_CSR_ROWS"] = _run(api, "hipSpMVRowsCSR", d, x, M)
+        out["CUDA_CSR_ROWS_WARP"] = _run(api, "hipSpMVWarpPerRowCSR", d, x, M)
+        return out
+    exact = {("hipSpMVRowsCSR", 0), ("hipSpMVRowsCSR", 1), ("tiles", True), ("stripes", 1), ("stripes", 2), "CUDA_CSR_ROWS"}
+    arrival = {("tiles", False), ("stripes", 0), "CUDA_CSR_ROWS_WARP"}          # sums in arrival order: equal to rounding, run to run
+    d = api.spMatCpyCSR(api.HostCSR(M, N, IRP, JA, AS))
+    assert api.lib.spmvHipUnitValue(C.byref(d.handle), C.byref(c)) == 1 and c.value == value
+    sb0 = None
+    fast = run_all(d)
+    if JA.size >= 1:
+        sb0 = api.lib.spmvHipStripesBytes(C.byref(d.handle))
+    d.free()
+    try:
+        api.lib.spmvHipSetUnitValues(0)
+        d = api.spMatCpyCSR(api.HostCSR(M, N, IRP, JA, AS))
+        assert api.lib.spmvHipUnitValue(C.byref(d.handle), None) == 0
+        plain = run_all(d)
+        sb1 = api.lib.spmvHipStripesBytes(C.byref(d.handle))
+        d.free()
+    finally:
+        api.lib.spmvHipSetUnitValues(1)
+    assert sb0 < sb1                                                            # no value array in the stripes format
+    for k, y in fast.items():
+        assert not np.isnan(y).any(), k
+        if k in exact:
+            assert np.array_equal(y, y_ref), k
+        else:
+            assert tight_error(IRP, JA, AS, x, y_ref, y) <= TIGHT, k
+        if k not in arrival:
+            assert np.array_equal(y, plain[k]), k
+    small = M * int(np.diff(IRP.astype(np.int64)).max(initial=0)) <= 20_000_000     # "wide": one 30 000-entry row would make 1.2 G ELL cells
+    if small:
+        # ELL with row lengths: the real cells are all `value`, the padding cells {0.0, column 0} are never touched
+        host = api.HostCSR(M, N, IRP, JA, AS)
+        ell = host.to_ell(with_row_lens=True)
+        api.lib.spmvHipSetEllRowLens(1)
+        dcsr = api.spMatCpyCSR(host)
+        mats = [("hipSpMVRowsELL", api.spMatCpyELL(ell.transpose()), True), ("hipSpMVRowsELLNNTransposed", api.spMatCpyELL(ell), True),
+                ("hipSpMVWarpsPerRowELLNTrasposed", api.spMatCpyELL(ell), False), ("hipSpMVRowsELL", api.csr_to_ell_device(dcsr, True), True),
+                ("hipSpMVRowsELLNNTransposed", api.csr_to_ell_device(dcsr, False), True)]
+        for launcher, de, bitwise in mats:
+            assert api.lib.spmvHipUnitValue(C.byref(de.handle), C.byref(c)) == (1 if JA.size else 0), launcher
+            y = _run(api, launcher, de, x, M)
+            if bitwise:
+                assert np.array_equal(y, y_ref + 0.0), launcher
+            else:
+                assert tight_error(IRP, JA, AS, x, y_ref, y) <= TIGHT, launcher
+            api.lib.spmvHipSetEllRowLens(0)                                         # all slots: padding is part of the sum, values are read
+            y = _run(api, launcher, de, x, M)
+            api.lib.spmvHipSetEllRowLens(1)
+            assert np.max(np.abs(y - y_ref), initial=0.0) <= GATE, launcher
+            de.free()
+        dcsr.free()
+        de = api.spMatCpyELL(host.to_ell(with_row_lens=False))                       # no row lengths uploaded: nothing to recognise
+        assert api.lib.spmvHipUnitValue(C.byref(de.handle), None) == 0
+        de.free()
+    AS2 = AS.copy()
+    AS2[AS2.size // 2] = np.nextafter(value, 10.0)                              # one value off by one ulp
+    d = api.spMatCpyCSR(api.HostCSR(M, N, IRP, JA, AS2))
+    assert api.lib.spmvHipUnitValue(C.byref(d.handle), None) == 0
+    y2_ref = oracle.csr_serial(IRP, JA, AS2, x)
+    assert np.array_equal(_run(api, "hipSpMVRowsCSR", d, x, M), y2_ref)
+    d.free()
+    if small:
+        de = api.spMatCpyELL(api.HostCSR(M, N, IRP, JA, AS2).to_ell(with_row_lens=True).transpose())
+        assert api.lib.spmvHipUnitValue(C.byref(de.handle), None) == 0
+        assert np.array_equal(_run(api, "hipSpMVRowsELL", de, x, M), y2_ref + 0.0)
+        de.free()
