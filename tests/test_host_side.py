@@ -413,3 +413,19 @@ def test_size_line_that_wraps_and_truncated_xz(tmp_path):
     t0 = time.time()
     assert H.extractInTmpFS(str(src).encode(), str(tmp_path / "cut.mtx").encode()) != 0
     assert time.time() - t0 < 5
+
+
+def test_structured_generators_write_pattern_files(tmp_path):
+    """kind | 16: the same structure as a `pattern` file (what the DIMACS10 graphs of the reference's report are): no value
+    column, and the loader gives every entry 1.0 (parser.c:59-61)."""
+    Mv, NZv, mx = C.c_ulong(), C.c_ulong(), C.c_ulong()
+    valued, pat = str(tmp_path / "v.mtx").encode(), str(tmp_path / "p.mtx").encode()
+    assert H.spmvSynthWriteMtx(valued, 1, 50_000, 0, 0, 5, C.byref(Mv), C.byref(NZv), C.byref(mx)) == 0
+    assert H.spmvSynthWriteMtx(pat, 1 | 16, 50_000, 0, 0, 5, C.byref(Mv), C.byref(NZv), C.byref(mx)) == 0
+    assert open(pat, "rb").readline() == b"%%MatrixMarket matrix coordinate pattern general\n"
+    assert os.path.getsize(pat) < os.path.getsize(valued)
+    a, b = H.MMtoCSR(valued).contents, H.MMtoCSR(pat).contents
+    assert (a.M, a.NZ) == (b.M, b.NZ) == (Mv.value, NZv.value)
+    assert np.array_equal(_arr(a.IRP, a.M + 1, np.int64), _arr(b.IRP, b.M + 1, np.int64))
+    assert np.array_equal(_arr(a.JA, a.NZ, np.int64), _arr(b.JA, b.NZ, np.int64))
+    assert np.all(_arr(b.AS, b.NZ, np.float64) == 1.0) and not np.all(_arr(a.AS, a.NZ, np.float64) == 1.0)
