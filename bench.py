@@ -59,7 +59,7 @@ def parse():
                    help="add `y_sha256`, the hash of the bytes of the timed kernel's full y (rank 0's copy), to the line: two runs with a "
                         "serial-order launcher (--launcher hipSpMVRowsCSR) must agree on it whatever the number of ranks")
     p.add_argument("--only-structured", default="",
-                   help="measure only the structured stand-in whose name contains this string (stencil3d, road, blocks; 'all' = the "
+                   help="measure only the structured stand-ins whose name contains this string, or equals it when it ends in '$' (stencil3d, road, blocks, pattern; 'all' = the "
                         "three) and print that block alone -- for profiling the ELL / CSR kernels on the reference's kind of matrix")
     p.add_argument("--groups", type=int, default=0, help="pin the row groups per rank of the exchange at N > 1")
     p.add_argument("--pieces", type=int, default=0, help="pin the pieces of y per rank for --exchange push")
@@ -783,7 +783,7 @@ def measure_structured(api, synth, torch, args, steps, warmup, only=""):
     out = {"note": "stand-ins shaped like the matrices of the reference's report, generated -> .mtx -> MMtoCSR/MMtoELL -> upload -> launchers; "
                    "`published` = the reference's own tables for the original matrix (other, unstated hardware)", "matrices": []}
     for spec in STRUCTURED:
-        if only and only != "all" and only not in spec["name"]:
+        if only and only != "all" and (only[:-1] != spec["name"] if only.endswith("$") else only not in spec["name"]):
             continue
         p0, p1, p2 = spec["p"]
         if args.scale != 1.0:

@@ -39,6 +39,9 @@ pstruct() {
   timeout -k 10 400 rocprofv3 --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum --output-format csv -d $O/$tag/pmc_write -- $B > $O/$tag.pmc2.log 2>&1
   echo "profiled $tag"
 }
-pstruct stencil stencil3d
-pstruct road road
+pstruct stencil 'stencil3d-500x100x100$'
+pstruct road 'road-12M$'
+# the same shapes as pattern files (all values 1.0: the kernels stream no values)
+pstruct stencil_pattern 'stencil3d-500x100x100-pattern$'
+pstruct road_pattern 'road-12M-pattern$'
 ls $O

@@ -68,7 +68,9 @@ for tag in wlname:
         traffic.setdefault(wlname[tag], {})[launcher] = tot
 # the structured stand-ins: one SpMV kernel per launcher, all in one run -> one table per matrix (time + HBM-side traffic per launch)
 STRUCT = {"stencil": ("stencil3d-500x100x100 (5 M rows, 88.9 M entries, 18 slots)", 88902800 * 12 + 5000000 * 20),
-          "road": ("road-12M (12 M rows, 25.7 M entries, 9 slots)", 25733999 * 12 + 12000000 * 20)}
+          "road": ("road-12M (12 M rows, 25.7 M entries, 9 slots)", 25733999 * 12 + 12000000 * 20),
+          "stencil_pattern": ("stencil3d-500x100x100 as a PATTERN file (all values 1.0: no value stream; 0.456 GB are left to move)", 88902800 * 12 + 5000000 * 20),
+          "road_pattern": ("road-12M as a PATTERN file (all values 1.0: no value stream; 0.343 GB are left to move)", 25733999 * 12 + 12000000 * 20)}
 SKEEP = KEEP + ("ell_",)
 for tag, (title, bcsr) in STRUCT.items():
     tr = collections.defaultdict(list)
